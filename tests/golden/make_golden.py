@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python.
+
+Run in the build container only (needs /root/reference; never on the GPU box):
+
+    python -B tests/golden/make_golden.py
+
+The reference cannot travel, so what is committed is data: seeds/configs of the
+synthetic inputs (moc_amd.synth, numpy Philox) plus the outputs the reference
+produced for them.  tests/test_oracle_golden.py pins oracle/moc_oracle.py to
+these files; the -m gpu tests compare the HIP path with them.
+
+How the reference is reached:
+  * utils/patch_selection_classifier{,_index}.py import as-is (torch only);
+  * main_moc.py has import-time side effects (argparse, checkpoint load), so
+    the definitions senet / slide_process / train / zs_evaluation / evaluation /
+    ablation_evaluation are taken from its AST and exec'd unmodified in a
+    namespace holding the names they use.
+"""
+import ast
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from sklearn.metrics import roc_auc_score
+from tqdm import tqdm
+
+from moc_amd import synth
+
+from utils.patch_selection_classifier_index import (  # noqa: E402  (reference)
+    index_topj_classifier, index_delta_diff_classifier,
+    index_delta_softmax_classifier, index_bottomk_irrel_classifier)
+from utils.patch_selection_classifier import (  # noqa: E402  (reference)
+    topj_pooling, delta_softmax_classifier_pooling, delta_diff_classifier_pooling,
+    bottomk_irrel_classifier_pooling)
+
+torch.set_num_threads(1)   # fixed reduction order inside aten on this host
+
+WANTED = {"senet", "slide_process", "train", "zs_evaluation", "evaluation", "ablation_evaluation"}
+
+
+def load_reference_main():
+    tree = ast.parse(open(os.path.join(REF, "main_moc.py")).read())
+    body = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in WANTED]
+    ns = dict(torch=torch, nn=nn, F=F, np=np, tqdm=tqdm, roc_auc_score=roc_auc_score,
+              index_topj_classifier=index_topj_classifier,
+              index_delta_diff_classifier=index_delta_diff_classifier,
+              index_delta_softmax_classifier=index_delta_softmax_classifier,
+              index_bottomk_irrel_classifier=index_bottomk_irrel_classifier,
+              topj_pooling=topj_pooling,
+              delta_softmax_classifier_pooling=delta_softmax_classifier_pooling,
+              delta_diff_classifier_pooling=delta_diff_classifier_pooling,
+              bottomk_irrel_classifier_pooling=bottomk_irrel_classifier_pooling)
+    exec(compile(ast.Module(body=body, type_ignores=[]), "main_moc.py", "exec"), ns)
+    return ns
+
+
+class FakeDataset:
+    """The attributes evaluation()/zs_evaluation() touch (dataset_generic.py:380-393)."""
+
+    def __init__(self, bags, labels, repeat_num=None):
+        self.bags, self.labels, self.repeat_num = bags, labels, repeat_num
+
+    def real_len(self):
+        return len(self.bags)
+
+    def __len__(self):
+        return self.repeat_num if self.repeat_num else len(self.bags)
+
+
+class FakeLoader:
+    """batch_size=1 default-collate items, as main_moc.py:381-385 unpacks them."""
+
+    def __init__(self, bags, labels, repeat_num=None):
+        self.dataset = FakeDataset(bags, labels, repeat_num)
+
+    def __iter__(self):
+        ds = self.dataset
+        for i in range(len(ds)):
+            k = i % ds.real_len()
+            x = ds.bags[k]
+            yield (x.unsqueeze(0), torch.tensor([ds.labels[k]]),
+                   torch.zeros(1, x.size(0), 2), [f"slide_{k}.h5"])
+
+    def __len__(self):
+        return len(self.dataset)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def i32(t):
+    return t.to(torch.int32).numpy()
+
+
+# --------------------------------------------------------------------------
+def gen_selectors():
+    """(1) the four selectors on seeded bags; index tensors value-ordered."""
+    out = {}
+    cases = []
+    cid = 0
+    for N in (128, 1000, 4096):
+        for C in (2, 3, 30):
+            for j in (10, 400):
+                seed = 7000 + cid
+                W, We = synth.make_bank(seed, 512, C)
+                x = synth.make_bag(seed + 500, N, 512, We, C, label=cid % C)
+                lg, lge = x @ W, x @ We
+                out[f"c{cid}_top"] = i32(index_topj_classifier(lg, [j]))
+                out[f"c{cid}_softmax"] = i32(index_delta_softmax_classifier(lg, [j]))
+                out[f"c{cid}_gap"] = i32(index_delta_diff_classifier(lg, [j]))
+                out[f"c{cid}_lowbg"] = i32(index_bottomk_irrel_classifier(lge, [j], C))
+                out[f"c{cid}_logits_ext"] = lge.numpy()
+                cases.append((cid, N, C, j, seed))
+                cid += 1
+    out["cases"] = np.array(cases, dtype=np.int64)
+    save("selectors", **out)
+
+
+def gen_slide_process(ref):
+    """(2) slide_process dicts: no mask, reference-drawn mask, discard subsets."""
+    out, cases = {}, []
+    cfgs = [  # (N, C, j, random_mask, discard)
+        (1000, 2, 100, False, []),
+        (1000, 2, 100, True, []),
+        (3000, 3, 400, True, []),
+        (300, 2, 400, True, []),          # N' < j  -> every kept row selected
+        (2000, 30, 50, False, []),
+        (1500, 2, 100, False, ["delta_diff"]),
+        (1500, 2, 100, True, ["topk", "bottomk"]),
+        (1500, 3, 100, False, ["delta_softmax", "delta_diff", "bottomk"]),
+        (257, 2, 10, True, []),
+    ]
+    for cid, (N, C, j, rm, discard) in enumerate(cfgs):
+        seed = 8000 + cid
+        W, We = synth.make_bank(seed, 512, C)
+        x = synth.make_bag(seed + 500, N, 512, We, C, label=cid % C)
+        torch.manual_seed(seed)
+        r = ref["slide_process"](x, W, We, C, topj=j, random_mask=rm, discard_classifiers=list(discard))
+        torch.manual_seed(seed)
+        mask = (torch.rand(N) > 0.5) if rm else torch.ones(N, dtype=torch.bool)
+        kept = x[mask]
+        assert torch.equal(kept[r["selected_index"]], r["selected_feat"])
+        out[f"c{cid}_mask"] = np.packbits(mask.numpy())
+        out[f"c{cid}_selected_index"] = np.asarray(r["selected_index"], dtype=np.int32)
+        out[f"c{cid}_top"] = r["logits_top_classifier"].numpy()
+        out[f"c{cid}_softmax"] = r["logits_delta_softmax_classifier"].numpy()
+        out[f"c{cid}_gap"] = r["logits_delta_diff_classifier"].numpy()
+        out[f"c{cid}_lowbg"] = r["logits_bottomk_irrel_classifier"].numpy()
+        dmask = sum(1 << k for k, n in enumerate(("topk", "delta_softmax", "delta_diff", "bottomk")) if n in discard)
+        cases.append((cid, N, C, j, int(rm), dmask, seed))
+    out["cases"] = np.array(cases, dtype=np.int64)
+    save("slide_process", **out)
+
+
+def gen_pooling():
+    """(3) topj_pooling and the three zs pooling variants, K in {1,10}, S<K edge."""
+    out, cases = {}, []
+    cid = 0
+    for N, C in ((5, 2), (64, 3), (2000, 2), (2000, 30)):
+        seed = 9000 + cid
+        W, We = synth.make_bank(seed, 512, C)
+        x = synth.make_bag(seed + 500, N, 512, We, C, label=0)
+        lg, lge = x @ W, x @ We
+        for K in (1, 10):
+            out[f"c{cid}_K{K}_topj"] = topj_pooling(lg, [K])[1][K].numpy()
+            out[f"c{cid}_K{K}_softmax"] = delta_softmax_classifier_pooling(lg, [K])[1][K].numpy()
+            out[f"c{cid}_K{K}_gap"] = delta_diff_classifier_pooling(lg, [K])[1][K].numpy()
+            out[f"c{cid}_K{K}_lowbg"] = bottomk_irrel_classifier_pooling(lge, [K], coords_list=C)[1][K].numpy()
+        p, pooled, idx = topj_pooling(lg, [10], return_indices=True)
+        out[f"c{cid}_topj_idx"] = i32(idx)
+        out[f"c{cid}_topj_pred"] = i32(p[10])
+        cases.append((cid, N, C, seed))
+        cid += 1
+    out["cases"] = np.array(cases, dtype=np.int64)
+    save("pooling", **out)
+
+
+def _args(C, j, K, discard=()):
+    return types.SimpleNamespace(disable_tqdm=True, n_classes=C, topj=j, topk=K,
+                                 discard_classifiers=list(discard), pretrain="conch",
+                                 ablation_study="none")
+
+
+def flat_params(model):
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy().copy()
+
+
+def flat_state(opt, key):
+    return torch.cat([opt.state[p][key].reshape(-1) for g in opt.param_groups for p in g["params"]]).numpy().copy()
+
+
+def gen_train(ref):
+    """(4) consecutive train steps from a seeded senet."""
+    out, cases = {}, []
+    cfgs = [  # (n_slides, N, C, j, K, discard)
+        (5, 1200, 2, 100, 10, []),
+        (6, 1500, 3, 400, 10, []),
+        (4, 256, 2, 400, 10, []),            # cfg-1 like: N' < j
+        (4, 1000, 2, 100, 10, ["delta_diff"]),
+        (30, 800, 30, 50, 10, []),
+    ]
+    for cid, (ns, N, C, j, K, discard) in enumerate(cfgs):
+        seed = 10000 + cid
+        W, We = synth.make_bank(seed, 512, C)
+        bags, labels = synth.make_slide_set(seed + 100, [N] * ns, 512, We, C)
+        ref["zeroshot_weights"], ref["zeroshot_weights_ext"] = W, We
+        torch.manual_seed(seed)
+        model = ref["senet"](512, 4)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        out[f"c{cid}_init"] = flat_params(model)
+        # one step at a time so per-step state can be recorded; the RNG stream is
+        # the same as one train() over all slides (nothing else draws from it)
+        torch.manual_seed(seed + 1)
+        masks = []
+        st = torch.get_rng_state()
+        for b in bags:
+            masks.append(torch.rand(b.size(0)) > 0.5)
+        torch.set_rng_state(st)
+        for s in range(ns):
+            loader = FakeLoader([bags[s]], [labels[s]])
+            ref["train"](model, loader, opt, "cpu", _args(C, j, K, discard))
+            if s == 0:
+                out[f"c{cid}_grad1"] = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy().copy()
+            if s in (0, ns - 1):
+                out[f"c{cid}_params_s{s}"] = flat_params(model)
+                out[f"c{cid}_m_s{s}"] = flat_state(opt, "exp_avg")
+                out[f"c{cid}_v_s{s}"] = flat_state(opt, "exp_avg_sq")
+        # per-step loss / pooled logits: one-pass rerun from the same init with
+        # F.cross_entropy observed (also checks stepwise == one train() call)
+        torch.manual_seed(seed)
+        model2 = ref["senet"](512, 4)
+        opt2 = torch.optim.Adam(model2.parameters(), lr=1e-3, weight_decay=1e-4)
+        torch.manual_seed(seed + 1)
+        rec = []
+        orig = F.cross_entropy
+
+        def hooked(inp, tgt, *a, **k):
+            v = orig(inp, tgt, *a, **k)
+            rec.append((float(v), inp.detach().numpy().copy()))
+            return v
+        F.cross_entropy = hooked
+        try:
+            ref["train"](model2, FakeLoader(bags, labels), opt2, "cpu", _args(C, j, K, discard))
+        finally:
+            F.cross_entropy = orig
+        assert np.array_equal(flat_params(model2), out[f"c{cid}_params_s{ns - 1}"]), "stepwise != one-pass"
+        out[f"c{cid}_loss"] = np.array([r[0] for r in rec], dtype=np.float64)
+        out[f"c{cid}_pooled"] = np.concatenate([r[1] for r in rec], 0)
+        out[f"c{cid}_masks"] = np.concatenate([np.packbits(m.numpy()) for m in masks])
+        dmask = sum(1 << k for k, n in enumerate(("topk", "delta_softmax", "delta_diff", "bottomk")) if n in discard)
+        cases.append((cid, ns, N, C, j, K, dmask, seed))
+    out["cases"] = np.array(cases, dtype=np.int64)
+    save("train", **out)
+
+
+def gen_eval(ref):
+    """(5) evaluation / zs_evaluation / ablation_evaluation dicts."""
+    out, cases = {}, []
+    cfgs = [(16, 900, 2, 100, 10, [], None), (18, 700, 3, 400, 10, [], 12),
+            (16, 900, 2, 100, 10, ["delta_softmax"], None), (60, 400, 30, 20, 10, [], None)]
+    for cid, (ns, N, C, j, K, discard, repeat_num) in enumerate(cfgs):
+        seed = 11000 + cid
+        W, We = synth.make_bank(seed, 512, C)
+        bags, labels = synth.make_slide_set(seed + 100, [N] * ns, 512, We, C)
+        ref["zeroshot_weights"], ref["zeroshot_weights_ext"] = W, We
+        torch.manual_seed(seed)
+        model = ref["senet"](512, 4)
+        out[f"c{cid}_init"] = flat_params(model)
+        a = _args(C, j, K, discard)
+        ev = ref["evaluation"](model, FakeLoader(bags, labels, repeat_num), "cpu", a)
+        out[f"c{cid}_eval"] = np.array([ev["loss"], ev["acc"], ev["auc"]], dtype=np.float64)
+        pools = (("topj", topj_pooling), ("delta_softmax", delta_softmax_classifier_pooling),
+                 ("delta_diff", delta_diff_classifier_pooling), ("bottomk", bottomk_irrel_classifier_pooling))
+        for name, fn in pools:
+            zs = ref["zs_evaluation"](FakeLoader(bags, labels, repeat_num), "cpu", a, pooling_func=fn)
+            out[f"c{cid}_zs_{name}"] = np.array([zs["loss"], zs["acc"], zs["auc"]], dtype=np.float64)
+        for mode in ("avg", "sum", "max"):
+            a.ablation_study = mode
+            ab = ref["ablation_evaluation"](FakeLoader(bags, labels, repeat_num), "cpu", a)
+            out[f"c{cid}_abl_{mode}"] = np.array([ab["loss"], ab["acc"], ab["auc"]], dtype=np.float64)
+        dmask = sum(1 << k for k, n in enumerate(("topk", "delta_softmax", "delta_diff", "bottomk")) if n in discard)
+        cases.append((cid, ns, N, C, j, K, dmask, repeat_num or 0, seed))
+    out["cases"] = np.array(cases, dtype=np.int64)
+    save("evaluation", **out)
+
+
+if __name__ == "__main__":
+    ref = load_reference_main()
+    gen_selectors()
+    gen_slide_process(ref)
+    gen_pooling()
+    gen_train(ref)
+    gen_eval(ref)
