@@ -1,0 +1,212 @@
+/*
+ * moc_hip.h -- C ABI of libmoc_hip.so: the MI355X (gfx950) kernels for the hot
+ * path of xmed-lab/MOC.
+ *
+ * The reference has no FFI of its own: its seam is a set
+ * of Python callables in main_moc.py and utils/patch_selection_classifier*.py.
+ * Each entry point below names the reference lines it replaces; the Python
+ * package moc_amd binds them with ctypes (INTEGRATION.md shows the stub a
+ * maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every pointer marked "device" is HIP device memory owned by the caller
+ *     (PyTorch tensors in practice); the library never allocates, frees or keeps
+ *     device memory and holds no state between calls;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     every call returns without synchronising the host;
+ *   - return value 0 = success; otherwise a MOC_E* code, with a message
+ *     available from moc_last_error() (thread local);
+ *   - all matrices are row-major and dense; bag rows must be 16-byte aligned
+ *     (D*elem_size % 16 == 0 and a 16-byte aligned base);
+ *   - "slot space": work arrays are indexed by slot, not by row of X; total_rows is the
+ *     number of slots (sum of the batch's slide sizes).  The kept (un-masked) rows of slide b occupy slots
+ *     [row_off[b], row_off[b] + n_kept[b]) of every per-row work array, in
+ *     ascending row order; with no mask n_kept[b] == rows of slide b.
+ */
+#ifndef MOC_HIP_H
+#define MOC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOC_ABI_VERSION 1
+
+enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
+
+/* storage type of the bag X; arithmetic is always fp32-accumulate */
+enum { MOC_F32 = 0, MOC_BF16 = 1 };
+
+/* bits of `discard_bits`, in the order of main_moc.py:341-350 */
+enum { MOC_SEL_TOPK = 1, MOC_SEL_DELTA_SOFTMAX = 2, MOC_SEL_DELTA_DIFF = 4, MOC_SEL_BOTTOMK = 8 };
+
+typedef void* moc_stream_t; /* hipStream_t */
+
+/* A batch of slides packed back to back in one [total_rows, D] array, plus the
+ * caller-allocated work arrays every stage reads/writes.  `stride` below is
+ * total_rows. */
+typedef struct moc_batch {
+    /* ---- inputs ---- */
+    const void*    X;          /* device [total_rows, D]                                  */
+    int32_t        dtype;      /* MOC_F32 | MOC_BF16                                     */
+    int32_t        D;          /* embedding dim (512 for CONCH)                          */
+    int64_t        total_rows;
+    int32_t        n_slides;
+    int32_t        max_rows;   /* max rows of any slide (host value, sizes the grids)    */
+    const int64_t* row_off;    /* device [n_slides+1], first SLOT of each slide (prefix
+                                  sum of the slide sizes)                                */
+    const int64_t* x_off;      /* device [n_slides], first row of each slide inside X, or
+                                  NULL = row_off (slides packed in batch order).  Lets a
+                                  batch visit resident slides in any order / repeatedly
+                                  (dataset_generic.py:380-393 repeat_num) without copies */
+    const uint8_t* mask;       /* device [total_rows] 0/1 keep flags, or NULL = keep all
+                                  (main_moc.py:329-331; drawn by the host, see moc_amd)  */
+    int32_t        C;          /* n_classes                                              */
+    int32_t        Ce;         /* columns of zeroshot_weights_ext (C + background)       */
+    int32_t        topj;       /* --topj                                                 */
+    int32_t        topk;       /* --topk                                                 */
+    uint32_t       discard_bits;
+    uint32_t       reserved;
+    /* ---- work arrays (device) ---- */
+    int32_t* kept;       /* [total_rows]      slot -> row index inside its slide (unused if mask==NULL) */
+    int32_t* n_kept;     /* [n_slides]                                                               */
+    float*   stats;      /* [2C+3, total_rows] per-slot: logits[C] | softmax[C] | gap | bg_sum | bg_max  */
+    uint8_t* sel_flag;   /* [total_rows]      union membership                                        */
+    int32_t* sel_idx;    /* [total_rows]      selected_index of slide b at [row_off[b], +n_sel[b])     */
+    int64_t* sel_row;    /* [total_rows]      same positions: row of X (packed) to gather             */
+    int32_t* n_sel;      /* [n_slides]        S                                                       */
+    float*   cand;       /* [2C+2, total_rows] per selected row: s_p[C] | s_sigma[C] | s_delta | s_beta */
+} moc_batch_t;
+
+/* The meta-learner ("senet", main_moc.py:299-312) and its Adam state
+ * (main_moc.py:316; torch.optim.Adam defaults otherwise).  All device fp32. */
+typedef struct moc_meta {
+    float *W1, *b1, *W2, *b2;         /* [H,D] [H] [4,H] [4]   H = 64                      */
+    float *m_W1, *m_b1, *m_W2, *m_b2; /* exp_avg      (may be NULL for forward-only use)   */
+    float *v_W1, *v_b1, *v_W2, *v_b2; /* exp_avg_sq                                        */
+    float *g_W1, *g_b1, *g_W2, *g_b2; /* gradient outputs (moc_train_grad), may be NULL    */
+    double lr, beta1, beta2, eps, weight_decay; /* the optimizer's Python floats, unrounded     */
+    int32_t H;                        /* hidden width, must be 64                          */
+    int32_t D;                        /* input width (== batch D)                          */
+    int64_t step;                     /* Adam steps already taken                          */
+} moc_meta_t;
+
+/* Work arrays of the meta-learner stage, caller allocated (device). */
+typedef struct moc_meta_ws {
+    float*   H1;        /* [total_rows, H]  relu(W1 x + b1) of every selected row            */
+    float*   gates;     /* [total_rows, 4]  lambda                                           */
+    float*   mixed;     /* [C, total_rows]  gated sum of the candidates ("final_logits")     */
+    float*   pooled;    /* [n_slides, C]    top-K mean per class                             */
+    int32_t* topk_idx;  /* [n_slides, C, topk] positions (0..S) of the pooled rows, by value */
+    int32_t* topk_cnt;  /* [n_slides, C]    min(K, S)                                        */
+    float*   loss;      /* [n_slides]       cross entropy                                    */
+    int32_t* pred;      /* [n_slides]       argmax of pooled                                 */
+    float*   pair_dh;   /* [C*topk, H]      backward scratch (one slide at a time)           */
+    int64_t* pair_row;  /* [C*topk]                                                          */
+    int32_t* n_pair;    /* [1]                                                               */
+} moc_meta_ws_t;
+
+int         moc_version(void);
+const char* moc_last_error(void);
+
+/* ---- classifier bank ------------------------------------------------------
+ * Re-lays [zeroshot_weights | zeroshot_weights_ext[:, C:]] (main_moc.py:336-337:
+ * the foreground columns come from W, the background ones from W_ext) into the
+ * MFMA operand image the score kernel streams from LDS.  For MOC_BF16 bags the
+ * fp32 weights are split into three bf16 terms so products stay exact in fp32.
+ * Redo whenever the weights change.  `fg_from_ext` != 0 takes the foreground
+ * columns from W_ext[:, :C] instead (bottomk_irrel_classifier_pooling,
+ * utils/patch_selection_classifier.py:151). */
+size_t moc_bank_bytes(int D, int Ce, int dtype);
+int    moc_prepare_bank(const float* W /*device [D,C]*/, const float* W_ext /*device [D,Ce]*/,
+                        int D, int C, int Ce, int dtype, int fg_from_ext,
+                        void* bank_out /*device, moc_bank_bytes*/, moc_stream_t stream);
+
+/* ---- phase A: parameter-free part of slide_process (main_moc.py:322-366) ---- */
+
+/* a1  row mask -> kept list + n_kept (main_moc.py:329-331).  No-op when mask==NULL. */
+int moc_mask_compact(const moc_batch_t* B, moc_stream_t stream);
+
+/* a2 + per-row parts of a4-a6, a9: X.[W|W_ext] and the row statistics
+ * (main_moc.py:336-337, :360-365; patch_selection_classifier_index.py:34, :46-48, :75).
+ * Also clears sel_flag. */
+int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t stream);
+
+/* The same statistics from an already computed logits matrix (device [N, Ct] row-major,
+ * first C columns foreground): stats_out is [2C+3, N].  For callers that hold logits, not
+ * bags (index_*_classifier / *_pooling, utils/patch_selection_classifier*.py).  With C == 1
+ * the gap column is +inf (the reference's topk(2) would raise). */
+int moc_row_stats(const float* logits, int64_t N, int Ct, int C, float* stats_out, moc_stream_t stream);
+
+/* a3-a7: the four top-j selectors and their union, as flags
+ * (patch_selection_classifier_index.py:17-87, main_moc.py:341-352). */
+int moc_select(const moc_batch_t* B, moc_stream_t stream);
+
+/* a7-a9: ascending compaction of the union -> sel_idx/sel_row/n_sel, candidate
+ * scores of the selected rows, optionally the gathered rows themselves
+ * (main_moc.py:354-366).  selected_feat: device [total_rows, D] in X's dtype or NULL. */
+int moc_gather_candidates(const moc_batch_t* B, void* selected_feat, moc_stream_t stream);
+
+/* all four above, in order */
+int moc_phase_a(const moc_batch_t* B, const void* bank, moc_stream_t stream);
+
+/* ---- phase B: meta-learner, pooling, loss, update ------------------------- */
+
+/* use_bits: which of the four gated terms enter the sum (bit i = term i).
+ * train: ~discard_bits & 15 (main_moc.py:396-403); eval: see moc_amd.main_moc
+ * for the reference's quirk (main_moc.py:486-492). */
+
+/* a10-a11 for slides [slide0, slide0+n): H1, gates, mixed */
+int moc_meta_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
+                     int slide0, int n, uint32_t use_bits, moc_stream_t stream);
+
+/* ablation_evaluation's parameter-free mixes (main_moc.py:538-553) in place of
+ * moc_meta_forward: mode 0 = avg (0.25 each), 1 = sum, 2 = max of the four candidates. */
+int moc_mix_fixed(const moc_batch_t* B, const moc_meta_ws_t* ws, int slide0, int n, int mode,
+                  moc_stream_t stream);
+
+/* a12-a13 (+a16 argmax) for slides [slide0, slide0+n): pooled, topk_idx, loss, pred.
+ * labels: device int64 [n_slides]. */
+int moc_pool_loss(const moc_batch_t* B, const moc_meta_ws_t* ws, const int64_t* labels,
+                  int slide0, int n, moc_stream_t stream);
+
+/* a13 + a16 alone: cross entropy and argmax of n rows of pooled logits [n, C]
+ * (F.cross_entropy(logits, lbl) and logits.argmax(dim=1), main_moc.py:433-434, :494-495). */
+int moc_ce_loss(const float* pooled, const int64_t* labels, int n, int C, float* loss, int32_t* pred,
+                moc_stream_t stream);
+
+/* a14: gradients of slide `slide`'s loss w.r.t. the four parameter tensors, written
+ * (not accumulated) to M->g_*.  Requires moc_meta_forward + moc_pool_loss of that slide. */
+int moc_train_grad(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
+                   const int64_t* labels, int slide, uint32_t use_bits, moc_stream_t stream);
+
+/* a15: one Adam step (coupled L2) from M->g_* scaled by grad_scale; uses step = M->step+1. */
+int moc_adam_step(const moc_meta_t* M, float grad_scale, moc_stream_t stream);
+
+/* a10-a15 fused: `n` consecutive meta-steps (one slide each, slides slide0..slide0+n-1 in
+ * order, one Adam step per slide: main_moc.py:380-410), parameters and Adam moments
+ * updated in place.  Per-slide loss/pooled land in ws->loss / ws->pooled. */
+int moc_train_steps(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
+                    const int64_t* labels, int slide0, int n, uint32_t use_bits,
+                    moc_stream_t stream);
+
+/* ---- generic pooling / ranking (a12, a17 and the index_* helpers) ----------
+ * For each segment s (rows seg_off[s] .. seg_off[s+1]) and class c: rank rows by
+ * keys[c*key_stride + row] (largest first, or smallest first when `smallest`),
+ * take k = min(K, len) and write mean(vals[c*val_stride + row]) over them to
+ * pooled[s*C + c] (utils/patch_selection_classifier.py:18-32, :35-80, :127-171).
+ * idx_out (nullable, int32 [n_seg, C, K]): chosen rows relative to the segment,
+ * ordered by key (ties: lower row first); cnt_out (nullable) [n_seg, C].
+ * K <= 4096. */
+int moc_topk_mean(const float* keys, int64_t key_stride, const float* vals, int64_t val_stride,
+                  const int64_t* seg_off, const int32_t* seg_len /*nullable*/, int n_seg, int C, int K,
+                  int smallest, float* pooled, int32_t* idx_out, int32_t* cnt_out,
+                  moc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOC_HIP_H */

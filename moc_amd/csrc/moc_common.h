@@ -1,0 +1,69 @@
+// Shared host/device helpers for libmoc_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/moc_hip.h"
+
+#define MOC_WAVE 64
+#define MOC_HIDDEN 64
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---- host-side error plumbing ------------------------------------------------
+void moc_set_error(const char* fmt, ...);
+#define MOC_FAIL(code, ...)          \
+    do {                             \
+        moc_set_error(__VA_ARGS__);  \
+        return (code);               \
+    } while (0)
+#define MOC_REQUIRE(cond, ...)                        \
+    do {                                              \
+        if (!(cond)) MOC_FAIL(MOC_EINVAL, __VA_ARGS__); \
+    } while (0)
+#define MOC_CHECK_LAUNCH(name)                                                       \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess)                                                       \
+            MOC_FAIL(MOC_ELAUNCH, "%s: launch failed: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline int moc_elem_size(int dtype) { return dtype == MOC_F32 ? 4 : 2; }
+static inline int moc_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers ------------------------------------------------------------
+// Order-preserving map float -> uint32 (larger float => larger key); -0 == +0.
+__device__ __forceinline__ uint32_t moc_key_desc(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u << 1) == 0) u = 0;  // canonical zero
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float moc_bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 bits (finite inputs)
+__device__ __forceinline__ uint16_t moc_f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// Exclusive prefix over a block of 0/1 flags.  `wave_tot` is LDS scratch with one
+// int per wave (+1).  Returns this thread's offset; *block_total gets the sum.
+// All threads of the block must call it; it contains two __syncthreads().
+__device__ __forceinline__ int moc_block_flag_scan(bool flag, int* wave_tot, int* block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int w = 0; w < nwave; ++w) {
+        const int t = wave_tot[w];
+        if (w < wave) off += t;
+        tot += t;
+    }
+    __syncthreads();
+    *block_total = tot;
+    return off + before;
+}

@@ -1,0 +1,481 @@
+// Phase B: the meta-learner ("senet") over the selected rows, the gated mix,
+// top-K mean pooling, cross entropy, the analytically sparse backward and Adam.
+//
+// Reference semantics:
+//   senet ................ main_moc.py:299-312  (Linear D->64, ReLU, Linear 64->4, Sigmoid)
+//   gated mix ............ main_moc.py:391-403 (train), :482-492 (eval)
+//   pooling .............. utils/patch_selection_classifier.py:18-32
+//   loss / backward ...... main_moc.py:406-409 (F.cross_entropy, loss.backward())
+//   Adam ................. main_moc.py:316, :410 (lr 1e-3, weight_decay 1e-4 coupled, torch defaults)
+//
+// Only the <= K*C rows that reach the top-K of some class carry gradient, so the
+// backward never touches the other S-K*C rows: d mixed[s,c] = dpooled[c]/k for
+// those (s,c) "pairs", then the usual chain through sigmoid, Linear, ReLU, Linear.
+//
+// Per meta-step four launches on one stream, no host synchronisation:
+//   meta_forward (S/16 workgroups, f32 MFMA) -> topk_mean (C workgroups)
+//   -> finish (1 workgroup: CE, pair gradients, Adam on b1/W2/b2)
+//   -> w1_update (W1 gradient from <= K*C gathered rows + Adam, one thread per element)
+#include "moc_common.h"
+
+int moc_check_batch(const moc_batch_t* B, const char* who);
+int moc_launch_topk_mean(const float* keys, int64_t key_stride, const float* vals, int64_t val_stride,
+                         const int64_t* seg_off, const int32_t* seg_len, int seg0, int n_seg, int C, int K,
+                         int smallest, float* pooled, int32_t* idx_out, int32_t* cnt_out, hipStream_t s);
+
+namespace {
+
+constexpr int H = MOC_HIDDEN;
+
+// Scalars exactly as torch hands them to its fp32 kernels: computed in Python doubles,
+// rounded to fp32 once.
+struct AdamCoef {
+    float wd, one_minus_b1, beta2, one_minus_b2, eps;
+    float neg_step_size;   // -(lr / (1 - beta1^t))
+    float bc2_sqrt;        // sqrt(1 - beta2^t)
+    float grad_scale;
+};
+
+// torch.optim.Adam (single-tensor path, coupled L2), operation by operation:
+//   g = g + wd*p ; m.lerp_(g, 1-b1) ; v.mul_(b2).addcmul_(g, g, 1-b2)
+//   denom = sqrt(v)/bc2_sqrt + eps ; p.addcdiv_(m, denom, -step_size)
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, const AdamCoef& k) {
+    g = __fadd_rn(g, __fmul_rn(k.wd, p));
+    m = __fadd_rn(m, __fmul_rn(k.one_minus_b1, __fsub_rn(g, m)));
+    v = __fadd_rn(__fmul_rn(v, k.beta2), __fmul_rn(__fmul_rn(k.one_minus_b2, g), g));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), k.bc2_sqrt), k.eps);
+    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(k.neg_step_size, m), denom));
+}
+
+// ------------------------------------------------------------------ forward
+struct FwdArgs {
+    const unsigned char* X;
+    const int64_t* row_off;
+    const int64_t* sel_row;
+    const int32_t* n_sel;
+    const float* cand;
+    const float *W1, *b1, *W2, *b2;
+    float *H1, *gates, *mixed;
+    int64_t stride;
+    int D, C, slide0;
+    uint32_t use_bits;
+};
+
+// grid (ceil(S_bound/16), n): one workgroup = 16 selected rows, wave w = hidden units 16w..16w+15.
+template <bool BF16>
+__global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
+    __shared__ float Hs[16][H + 1];
+    __shared__ float Gs[16][4];
+    const int b = a.slide0 + blockIdx.y;
+    const int64_t base = a.row_off[b];
+    const int S = a.n_sel[b];
+    const int row0 = blockIdx.x * 16;
+    if (row0 >= S) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int ESZ = BF16 ? 2 : 4;
+    const int s_c = min(row0 + (lane & 15), S - 1);
+    const unsigned char* xp = a.X + a.sel_row[base + s_c] * (int64_t)a.D * ESZ + (lane >> 4) * 16;
+    const float* wp = a.W1 + (int64_t)(wave * 16 + (lane & 15)) * a.D;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF16) {
+        // 16 B of x = 8 bf16 = k offsets kk*32 + (lane>>4)*8 + j; W1 row read at the same k
+        for (int kk = 0; kk < a.D / 32; ++kk) {
+            const uint4 xv = *reinterpret_cast<const uint4*>(xp + kk * 64);
+            const float4 w0 = *reinterpret_cast<const float4*>(wp + kk * 32 + (lane >> 4) * 8);
+            const float4 w1 = *reinterpret_cast<const float4*>(wp + kk * 32 + (lane >> 4) * 8 + 4);
+            const uint32_t xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            const float ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xs[j] << 16), ws[2 * j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xs[j] & 0xFFFF0000u), ws[2 * j + 1], acc, 0, 0, 0);
+            }
+        }
+    } else {
+        for (int kq = 0; kq < a.D / 16; ++kq) {
+            const float4 xv = *reinterpret_cast<const float4*>(xp + kq * 64);
+            const float4 wv = *reinterpret_cast<const float4*>(wp + kq * 16 + (lane >> 4) * 4);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, wv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.y, wv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.z, wv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.w, wv.w, acc, 0, 0, 0);
+        }
+    }
+    {   // acc[i] = pre-activation of row (lane>>4)*4+i, hidden unit wave*16 + (lane&15)
+        const int hcol = wave * 16 + (lane & 15);
+        const float bias = a.b1[hcol];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Hs[(lane >> 4) * 4 + i][hcol] = fmaxf(__fadd_rn(acc[i], bias), 0.f);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * H; e += 256) {
+        const int r = e >> 6, h = e & 63;
+        if (row0 + r < S) a.H1[(base + row0 + r) * H + h] = Hs[r][h];
+    }
+    if (threadIdx.x < 64) {
+        const int r = threadIdx.x >> 2, i = threadIdx.x & 3;
+        float z = 0.f;
+        for (int h = 0; h < H; ++h) z = fmaf(Hs[r][h], a.W2[i * H + h], z);
+        z += a.b2[i];
+        const float g = 1.f / (1.f + expf(-z));
+        Gs[r][i] = g;
+        if (row0 + r < S) a.gates[(base + row0 + r) * 4 + i] = g;
+    }
+    __syncthreads();
+    const int C = a.C;
+    for (int e = threadIdx.x; e < 16 * C; e += 256) {
+        const int r = e & 15, c = e >> 4;
+        if (row0 + r >= S) continue;
+        const float* cd = a.cand + base + row0 + r;
+        const float s0 = cd[(int64_t)c * a.stride], s1 = cd[(int64_t)(C + c) * a.stride];
+        const float s2 = cd[(int64_t)(2 * C) * a.stride], s3 = cd[(int64_t)(2 * C + 1) * a.stride];
+        float v = 0.f;   // 0 + x == x exactly, so this is the reference's running sum in both modes
+        if (a.use_bits & 1u) v = __fadd_rn(v, __fmul_rn(Gs[r][0], s0));
+        if (a.use_bits & 2u) v = __fadd_rn(v, __fmul_rn(Gs[r][1], s1));
+        if (a.use_bits & 4u) v = __fadd_rn(v, __fmul_rn(Gs[r][2], s2));
+        if (a.use_bits & 8u) v = __fadd_rn(v, __fmul_rn(Gs[r][3], s3));
+        a.mixed[(int64_t)c * a.stride + base + row0 + r] = v;
+    }
+}
+
+// ablation mixes (main_moc.py:538-553): grid (ceil(S_bound/256), n), thread -> selected row
+__global__ __launch_bounds__(256) void fixed_mix_kernel(FwdArgs a, int mode) {
+    const int b = a.slide0 + blockIdx.y;
+    const int64_t base = a.row_off[b];
+    const int S = a.n_sel[b], C = a.C;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    const float* cd = a.cand + base + s;
+    const float s2 = cd[(int64_t)(2 * C) * a.stride], s3 = cd[(int64_t)(2 * C + 1) * a.stride];
+    for (int c = 0; c < C; ++c) {
+        const float s0 = cd[(int64_t)c * a.stride], s1 = cd[(int64_t)(C + c) * a.stride];
+        float v;
+        if (mode == 0) v = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(0.25f, s0), __fmul_rn(0.25f, s1)), __fmul_rn(0.25f, s2)), __fmul_rn(0.25f, s3));
+        else if (mode == 1) v = __fadd_rn(__fadd_rn(__fadd_rn(s0, s1), s2), s3);
+        else v = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+        a.mixed[(int64_t)c * a.stride + base + s] = v;
+    }
+}
+
+// ------------------------------------------------------------------ loss (+ pair gradients)
+struct FinishArgs {
+    const int64_t* row_off;
+    const int64_t* sel_row;
+    const int32_t* n_sel;
+    const float* cand;
+    const float *H1, *gates, *pooled;
+    const int32_t *topk_idx, *topk_cnt;
+    const int64_t* labels;
+    float* loss;
+    int32_t* pred;
+    // train only
+    float *W2, *b2, *b1;
+    float *m_W2, *m_b2, *m_b1, *v_W2, *v_b2, *v_b1;
+    float *g_W2, *g_b2, *g_b1;
+    float* pair_dh;
+    int64_t* pair_row;
+    int32_t* n_pair;
+    int64_t stride;
+    int C, K, slide0, train, apply_adam;
+    uint32_t use_bits;
+    AdamCoef adam;
+};
+
+// grid (n): one workgroup per slide.  Eval: CE + argmax only.  Train (n == 1): also the
+// gradient "pairs" and the gradient/Adam of b1, W2, b2.
+__global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float dpool[256];   // d loss / d pooled[c]
+    const int b = a.slide0 + blockIdx.x, C = a.C;
+    const float* x = a.pooled + (int64_t)b * C;
+    const int y = (int)a.labels[b];
+    if (threadIdx.x == 0) {
+        float mx = -INFINITY;
+        int arg = 0;
+        for (int c = 0; c < C; ++c) if (x[c] > mx) { mx = x[c]; arg = c; }
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+        const float lse = mx + logf(se);
+        a.loss[b] = lse - x[y];
+        a.pred[b] = arg;
+        if (a.train) for (int c = 0; c < C; ++c) dpool[c] = expf(x[c] - lse) - (c == y ? 1.f : 0.f);
+    }
+    if (!a.train) return;
+    __syncthreads();
+
+    const int64_t base = a.row_off[b];
+    // pairs p = (c, r): r-th pooled row of class c.  n_pair = sum_c cnt[c] <= C*K
+    float* dz = reinterpret_cast<float*>(smem);                 // [P][4]
+    int* prow = reinterpret_cast<int*>(dz + (size_t)C * a.K * 4);   // [P] position s of the pair's row
+    // every class pools the same number of rows: cnt = min(K, S)
+    const int cnt = a.topk_cnt[(int64_t)b * C];
+    const int P = C * cnt;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const int c = p / cnt, r = p - c * cnt;
+        const int s = a.topk_idx[((int64_t)b * C + c) * a.K + r];
+        prow[p] = s;
+        const float g = dpool[c] / (float)cnt;
+        const float* cd = a.cand + base + s;
+        const float sc[4] = {cd[(int64_t)c * a.stride], cd[(int64_t)(C + c) * a.stride],
+                             cd[(int64_t)(2 * C) * a.stride], cd[(int64_t)(2 * C + 1) * a.stride]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float lam = a.gates[(base + s) * 4 + i];
+            const float dlam = (a.use_bits >> i & 1u) ? g * sc[i] : 0.f;
+            dz[p * 4 + i] = dlam * lam * (1.f - lam);
+        }
+        a.pair_row[p] = a.sel_row[base + s];
+    }
+    if (threadIdx.x == 0) *a.n_pair = P;
+    __syncthreads();
+    // dh[p][h] = (sum_i dz[p][i] * W2[i][h]) * [H1 > 0]
+    for (int e = threadIdx.x; e < P * H; e += 256) {
+        const int p = e >> 6, h = e & 63;
+        float v = 0.f;
+        for (int i = 0; i < 4; ++i) v = fmaf(dz[p * 4 + i], a.W2[i * H + h], v);
+        a.pair_dh[e] = a.H1[(base + prow[p]) * H + h] > 0.f ? v : 0.f;
+    }
+    __syncthreads();   // W2 fully read (and pair_dh visible to this workgroup) before it is updated
+    const float gs = a.adam.grad_scale;
+    {   // W2 [4][H]: thread t -> (i = t>>6, h = t&63)
+        const int i = threadIdx.x >> 6, h = threadIdx.x & 63;
+        float g = 0.f;
+        for (int p = 0; p < P; ++p) g = fmaf(dz[p * 4 + i], a.H1[(base + prow[p]) * H + h], g);
+        if (a.apply_adam) adam_update(a.W2[threadIdx.x], a.m_W2[threadIdx.x], a.v_W2[threadIdx.x], g * gs, a.adam);
+        else a.g_W2[threadIdx.x] = g;
+    }
+    if (threadIdx.x < 4) {
+        float g = 0.f;
+        for (int p = 0; p < P; ++p) g += dz[p * 4 + threadIdx.x];
+        if (a.apply_adam) adam_update(a.b2[threadIdx.x], a.m_b2[threadIdx.x], a.v_b2[threadIdx.x], g * gs, a.adam);
+        else a.g_b2[threadIdx.x] = g;
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + H) {
+        const int h = threadIdx.x - 64;
+        float g = 0.f;
+        for (int p = 0; p < P; ++p) g += a.pair_dh[p * H + h];
+        if (a.apply_adam) adam_update(a.b1[h], a.m_b1[h], a.v_b1[h], g * gs, a.adam);
+        else a.g_b1[h] = g;
+    }
+}
+
+// ------------------------------------------------------------------ W1 gradient (+ Adam)
+struct W1Args {
+    const unsigned char* X;
+    const float* pair_dh;
+    const int64_t* pair_row;
+    const int32_t* n_pair;
+    float *W1, *m_W1, *v_W1, *g_W1;
+    int D, apply_adam;
+    AdamCoef adam;
+};
+
+// grid (H*D/256): thread -> element (h, d); dW1[h][d] = sum_p dh[p][h] * x_p[d]
+template <bool BF16>
+__global__ __launch_bounds__(256) void w1_update_kernel(W1Args a) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int h = e / a.D, d = e - h * a.D;
+    const int P = *a.n_pair;
+    float g = 0.f;
+    for (int p = 0; p < P; ++p) {
+        const int64_t row = a.pair_row[p];
+        float xv;
+        if constexpr (BF16) xv = moc_bf16_to_f32(reinterpret_cast<const uint16_t*>(a.X)[row * a.D + d]);
+        else xv = reinterpret_cast<const float*>(a.X)[row * a.D + d];
+        g = fmaf(a.pair_dh[p * H + h], xv, g);
+    }
+    if (a.apply_adam) adam_update(a.W1[e], a.m_W1[e], a.v_W1[e], g * a.adam.grad_scale, a.adam);
+    else a.g_W1[e] = g;
+}
+
+// gradients already in g_* (e.g. after an all-reduce): plain Adam over all four tensors
+__global__ __launch_bounds__(256) void adam_all_kernel(moc_meta_t M, int D, AdamCoef k) {
+    const int nW1 = H * D, n = nW1 + H + 4 * H + 4;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float *p, *m, *v, *g;
+    int o = e;
+    if (o < nW1) { p = M.W1; m = M.m_W1; v = M.v_W1; g = M.g_W1; }
+    else if ((o -= nW1) < H) { p = M.b1; m = M.m_b1; v = M.v_b1; g = M.g_b1; }
+    else if ((o -= H) < 4 * H) { p = M.W2; m = M.m_W2; v = M.v_W2; g = M.g_W2; }
+    else { o -= 4 * H; p = M.b2; m = M.m_b2; v = M.v_b2; g = M.g_b2; }
+    adam_update(p[o], m[o], v[o], g[o] * k.grad_scale, k);
+}
+
+AdamCoef adam_coef(const moc_meta_t* M, int64_t step, float grad_scale) {
+    AdamCoef k;
+    k.wd = (float)M->weight_decay;
+    k.one_minus_b1 = (float)(1.0 - M->beta1);
+    k.beta2 = (float)M->beta2;
+    k.one_minus_b2 = (float)(1.0 - M->beta2);
+    k.eps = (float)M->eps;
+    const double bc1 = 1.0 - pow(M->beta1, (double)step);
+    const double bc2 = 1.0 - pow(M->beta2, (double)step);
+    k.neg_step_size = (float)(-(M->lr / bc1));
+    k.bc2_sqrt = (float)sqrt(bc2);
+    k.grad_scale = grad_scale;
+    return k;
+}
+
+int check_meta(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const char* who,
+               bool need_adam, bool need_grad) {
+    MOC_REQUIRE(M && ws, "%s: null meta/ws", who);
+    MOC_REQUIRE(M->H == H, "%s: hidden width %d unsupported (must be %d)", who, M->H, H);
+    MOC_REQUIRE(M->D == B->D, "%s: meta D=%d != batch D=%d", who, M->D, B->D);
+    MOC_REQUIRE(M->W1 && M->b1 && M->W2 && M->b2, "%s: null parameter", who);
+    MOC_REQUIRE(ws->H1 && ws->gates && ws->mixed && ws->pooled && ws->topk_idx && ws->topk_cnt && ws->loss && ws->pred,
+                "%s: null work array", who);
+    MOC_REQUIRE(B->sel_row && B->n_sel && B->cand, "%s: batch has no phase-A outputs", who);
+    MOC_REQUIRE(B->topk <= 256 && B->C <= 256, "%s: topk/C too large for the fused step (<= 256)", who);
+    if (need_adam)
+        MOC_REQUIRE(M->m_W1 && M->m_b1 && M->m_W2 && M->m_b2 && M->v_W1 && M->v_b1 && M->v_W2 && M->v_b2,
+                    "%s: null Adam state", who);
+    if (need_grad) MOC_REQUIRE(M->g_W1 && M->g_b1 && M->g_W2 && M->g_b2, "%s: null gradient output", who);
+    if (need_adam || need_grad) MOC_REQUIRE(ws->pair_dh && ws->pair_row && ws->n_pair, "%s: null backward scratch", who);
+    return MOC_OK;
+}
+
+int s_bound(const moc_batch_t* B) {
+    const int64_t by_sel = (int64_t)B->topj * (2 * B->C + 2);
+    return (int)(by_sel < B->max_rows ? by_sel : B->max_rows);
+}
+
+int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, int slide0, int n,
+                   uint32_t use_bits, hipStream_t s) {
+    FwdArgs a;
+    a.X = (const unsigned char*)B->X; a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel;
+    a.cand = B->cand; a.W1 = M->W1; a.b1 = M->b1; a.W2 = M->W2; a.b2 = M->b2;
+    a.H1 = ws->H1; a.gates = ws->gates; a.mixed = ws->mixed; a.stride = B->total_rows;
+    a.D = B->D; a.C = B->C; a.slide0 = slide0; a.use_bits = use_bits;
+    dim3 grid(moc_cdiv(s_bound(B), 16), n);
+    if (B->dtype == MOC_BF16) meta_forward_kernel<true><<<grid, 256, 0, s>>>(a);
+    else meta_forward_kernel<false><<<grid, 256, 0, s>>>(a);
+    MOC_CHECK_LAUNCH("moc_meta_forward");
+    return MOC_OK;
+}
+
+int launch_pool(const moc_batch_t* B, const moc_meta_ws_t* ws, int slide0, int n, hipStream_t s) {
+    return moc_launch_topk_mean(ws->mixed, B->total_rows, ws->mixed, B->total_rows, B->row_off, B->n_sel,
+                                slide0, n, B->C, B->topk, 0, ws->pooled, ws->topk_idx, ws->topk_cnt, s);
+}
+
+int launch_finish(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels,
+                  int slide0, int n, int train, int apply_adam, uint32_t use_bits, const AdamCoef& k, hipStream_t s) {
+    FinishArgs a;
+    a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel; a.cand = B->cand;
+    a.H1 = ws->H1; a.gates = ws->gates; a.pooled = ws->pooled; a.topk_idx = ws->topk_idx; a.topk_cnt = ws->topk_cnt;
+    a.labels = labels; a.loss = ws->loss; a.pred = ws->pred;
+    a.W2 = M->W2; a.b2 = M->b2; a.b1 = M->b1;
+    a.m_W2 = M->m_W2; a.m_b2 = M->m_b2; a.m_b1 = M->m_b1; a.v_W2 = M->v_W2; a.v_b2 = M->v_b2; a.v_b1 = M->v_b1;
+    a.g_W2 = M->g_W2; a.g_b2 = M->g_b2; a.g_b1 = M->g_b1;
+    a.pair_dh = ws->pair_dh; a.pair_row = ws->pair_row; a.n_pair = ws->n_pair;
+    a.stride = B->total_rows; a.C = B->C; a.K = B->topk; a.slide0 = slide0; a.train = train;
+    a.apply_adam = apply_adam; a.use_bits = use_bits; a.adam = k;
+    const size_t smem = train ? (size_t)B->C * B->topk * (4 * sizeof(float) + sizeof(int)) : 0;
+    MOC_REQUIRE(smem <= 64 * 1024, "finish: C*topk = %d too large", B->C * B->topk);
+    finish_kernel<<<n, 256, smem, s>>>(a);
+    MOC_CHECK_LAUNCH("moc_finish");
+    return MOC_OK;
+}
+
+int launch_w1(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, int apply_adam,
+              const AdamCoef& k, hipStream_t s) {
+    W1Args a;
+    a.X = (const unsigned char*)B->X; a.pair_dh = ws->pair_dh; a.pair_row = ws->pair_row; a.n_pair = ws->n_pair;
+    a.W1 = M->W1; a.m_W1 = M->m_W1; a.v_W1 = M->v_W1; a.g_W1 = M->g_W1; a.D = B->D; a.apply_adam = apply_adam; a.adam = k;
+    const int grid = H * B->D / 256;
+    if (B->dtype == MOC_BF16) w1_update_kernel<true><<<grid, 256, 0, s>>>(a);
+    else w1_update_kernel<false><<<grid, 256, 0, s>>>(a);
+    MOC_CHECK_LAUNCH("moc_w1_update");
+    return MOC_OK;
+}
+
+}  // namespace
+
+extern "C" int moc_meta_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
+                                int slide0, int n, uint32_t use_bits, moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_meta_forward")) return rc;
+    if (int rc = check_meta(B, M, ws, "moc_meta_forward", false, false)) return rc;
+    MOC_REQUIRE(slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_meta_forward: bad slide range");
+    return launch_forward(B, M, ws, slide0, n, use_bits, (hipStream_t)stream);
+}
+
+extern "C" int moc_mix_fixed(const moc_batch_t* B, const moc_meta_ws_t* ws, int slide0, int n, int mode,
+                             moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_mix_fixed")) return rc;
+    MOC_REQUIRE(ws && ws->mixed && B->n_sel && B->cand, "moc_mix_fixed: null work array");
+    MOC_REQUIRE(slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_mix_fixed: bad slide range");
+    MOC_REQUIRE(mode >= 0 && mode <= 2, "moc_mix_fixed: mode %d not in {0 avg, 1 sum, 2 max}", mode);
+    FwdArgs a = {};
+    a.row_off = B->row_off; a.n_sel = B->n_sel; a.cand = B->cand; a.mixed = ws->mixed;
+    a.stride = B->total_rows; a.C = B->C; a.slide0 = slide0;
+    fixed_mix_kernel<<<dim3(moc_cdiv(s_bound(B), 256), n), 256, 0, (hipStream_t)stream>>>(a, mode);
+    MOC_CHECK_LAUNCH("moc_mix_fixed");
+    return MOC_OK;
+}
+
+extern "C" int moc_pool_loss(const moc_batch_t* B, const moc_meta_ws_t* ws, const int64_t* labels,
+                             int slide0, int n, moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_pool_loss")) return rc;
+    MOC_REQUIRE(ws && labels, "moc_pool_loss: null ws/labels");
+    MOC_REQUIRE(slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_pool_loss: bad slide range");
+    MOC_REQUIRE(B->C <= 256, "moc_pool_loss: C > 256");
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = launch_pool(B, ws, slide0, n, s)) return rc;
+    moc_meta_t none = {};
+    AdamCoef k = {};
+    return launch_finish(B, &none, ws, labels, slide0, n, 0, 0, 0, k, s);
+}
+
+extern "C" int moc_ce_loss(const float* pooled, const int64_t* labels, int n, int C, float* loss, int32_t* pred,
+                           moc_stream_t stream) {
+    MOC_REQUIRE(pooled && labels && loss && pred, "moc_ce_loss: null pointer");
+    MOC_REQUIRE(n >= 1 && C >= 1 && C <= 256, "moc_ce_loss: bad n=%d C=%d (C <= 256)", n, C);
+    FinishArgs a = {};
+    a.pooled = pooled; a.labels = labels; a.loss = loss; a.pred = pred; a.C = C; a.slide0 = 0; a.train = 0;
+    finish_kernel<<<n, 256, 0, (hipStream_t)stream>>>(a);
+    MOC_CHECK_LAUNCH("moc_ce_loss");
+    return MOC_OK;
+}
+
+extern "C" int moc_train_grad(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
+                              const int64_t* labels, int slide, uint32_t use_bits, moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_train_grad")) return rc;
+    if (int rc = check_meta(B, M, ws, "moc_train_grad", false, true)) return rc;
+    MOC_REQUIRE(labels && slide >= 0 && slide < B->n_slides, "moc_train_grad: bad labels/slide");
+    hipStream_t s = (hipStream_t)stream;
+    AdamCoef k = {};
+    k.grad_scale = 1.f;
+    if (int rc = launch_finish(B, M, ws, labels, slide, 1, 1, 0, use_bits, k, s)) return rc;
+    return launch_w1(B, M, ws, 0, k, s);
+}
+
+extern "C" int moc_adam_step(const moc_meta_t* M, float grad_scale, moc_stream_t stream) {
+    MOC_REQUIRE(M && M->H == H && M->D > 0, "moc_adam_step: bad meta");
+    MOC_REQUIRE(M->W1 && M->m_W1 && M->v_W1 && M->g_W1 && M->b1 && M->m_b1 && M->v_b1 && M->g_b1 &&
+                M->W2 && M->m_W2 && M->v_W2 && M->g_W2 && M->b2 && M->m_b2 && M->v_b2 && M->g_b2,
+                "moc_adam_step: null tensor");
+    const AdamCoef k = adam_coef(M, M->step + 1, grad_scale);
+    const int n = H * M->D + H + 4 * H + 4;
+    adam_all_kernel<<<moc_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(*M, M->D, k);
+    MOC_CHECK_LAUNCH("moc_adam_step");
+    return MOC_OK;
+}
+
+extern "C" int moc_train_steps(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
+                               const int64_t* labels, int slide0, int n, uint32_t use_bits,
+                               moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_train_steps")) return rc;
+    if (int rc = check_meta(B, M, ws, "moc_train_steps", true, false)) return rc;
+    MOC_REQUIRE(labels && slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_train_steps: bad labels/slide range");
+    hipStream_t s = (hipStream_t)stream;
+    for (int t = 0; t < n; ++t) {
+        const int b = slide0 + t;
+        const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f);
+        if (int rc = launch_forward(B, M, ws, b, 1, use_bits, s)) return rc;
+        if (int rc = launch_pool(B, ws, b, 1, s)) return rc;
+        if (int rc = launch_finish(B, M, ws, labels, b, 1, 1, 1, use_bits, k, s)) return rc;
+        if (int rc = launch_w1(B, M, ws, 1, k, s)) return rc;
+    }
+    return MOC_OK;
+}

@@ -1,0 +1,340 @@
+// Phase A, part 1: classifier-bank preparation, row-mask compaction and the
+// streaming score pass  X . [W | W_ext[:, C:]]  with its per-row statistics.
+//
+// Reference semantics: main_moc.py:329-337 (mask, two matmuls), :360-365 and
+// utils/patch_selection_classifier_index.py:34, :46-48, :75 (per-row keys).
+//
+// Kernel shape (gfx950): one wave owns a 16-row tile.  The tile's rows are loaded
+// straight into MFMA A-fragment registers (16 B per lane per k-step), the bank
+// image sits in LDS in B-fragment order (one conflict-free ds_read_b128 per
+// MFMA), products accumulate in fp32:
+//   bf16 bags: v_mfma_f32_16x16x32_bf16 against a 3-term bf16 split of the fp32
+//              weights (hi+mid+lo carries 24 mantissa bits, every bf16*bf16
+//              product is exact in fp32);
+//   fp32 bags: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain).
+// The 16 x Ct result goes through a per-wave LDS tile so that one lane per row
+// can form softmax / top-2 gap / background sum+max, which are stored
+// column-major ([stat][slot]) for the column-wise selectors that follow.
+#include "moc_common.h"
+
+namespace {
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ------------------------------------------------------------------ bank image
+__device__ __forceinline__ float bank_elem(const float* W, const float* We, int C, int Ce,
+                                           int fg_from_ext, int k, int n) {
+    if (n >= Ce) return 0.f;
+    if (n < C && !fg_from_ext) return W[(int64_t)k * C + n];
+    return We[(int64_t)k * Ce + n];
+}
+
+// bf16 image: [nt][kk][term][lane][8] bf16, element j of lane l = Wcat[kk*32 + (l>>4)*8 + j][nt*16 + (l&15)]
+__global__ void prepare_bank_bf16_kernel(const float* W, const float* We, int D, int C, int Ce,
+                                         int fg_from_ext, uint16_t* out) {
+    const int KK = D / 32, NT = (Ce + 15) / 16;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NT * KK * 64) return;
+    const int lane = idx & 63, kk = (idx >> 6) % KK, nt = (idx >> 6) / KK;
+    const int n = nt * 16 + (lane & 15);
+    uint16_t* o = out + ((int64_t)(nt * KK + kk) * 3 * 64 + lane) * 8;
+    for (int j = 0; j < 8; ++j) {
+        const int k = kk * 32 + (lane >> 4) * 8 + j;
+        const float w = bank_elem(W, We, C, Ce, fg_from_ext, k, n);
+        const uint16_t hi = moc_f32_to_bf16_rne(w);
+        const float r1 = w - moc_bf16_to_f32(hi);
+        const uint16_t mid = moc_f32_to_bf16_rne(r1);
+        const float r2 = r1 - moc_bf16_to_f32(mid);
+        const uint16_t lo = moc_f32_to_bf16_rne(r2);
+        o[j] = hi;
+        o[64 * 8 + j] = mid;
+        o[2 * 64 * 8 + j] = lo;
+    }
+}
+
+// f32 image: [nt][kq][lane][4] float, element m of lane l = Wcat[kq*16 + (l>>4)*4 + m][nt*16 + (l&15)]
+__global__ void prepare_bank_f32_kernel(const float* W, const float* We, int D, int C, int Ce,
+                                        int fg_from_ext, float* out) {
+    const int KQ = D / 16, NT = (Ce + 15) / 16;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NT * KQ * 64) return;
+    const int lane = idx & 63, kq = (idx >> 6) % KQ, nt = (idx >> 6) / KQ;
+    const int n = nt * 16 + (lane & 15);
+    float* o = out + (int64_t)idx * 4;
+    for (int m = 0; m < 4; ++m)
+        o[m] = bank_elem(W, We, C, Ce, fg_from_ext, kq * 16 + (lane >> 4) * 4 + m, n);
+}
+
+// ------------------------------------------------------------------ mask -> kept
+__global__ __launch_bounds__(1024) void mask_compact_kernel(const uint8_t* mask, const int64_t* row_off,
+                                                            int32_t* kept, int32_t* n_kept) {
+    __shared__ int wave_tot[17];
+    const int b = blockIdx.x;
+    const int64_t base = row_off[b];
+    const int n = (int)(row_off[b + 1] - base);
+    int running = 0;
+    for (int c0 = 0; c0 < n; c0 += blockDim.x) {
+        const int i = c0 + threadIdx.x;
+        const bool keep = i < n && mask[base + i] != 0;
+        int tot;
+        const int pos = moc_block_flag_scan(keep, wave_tot, &tot);
+        if (keep) kept[base + running + pos] = i;
+        running += tot;
+    }
+    if (threadIdx.x == 0) n_kept[b] = running;
+}
+
+// ------------------------------------------------------------------ score pass
+struct ScoresArgs {
+    const unsigned char* X;
+    const unsigned char* bank;
+    const int64_t* row_off;
+    const int64_t* x_off;    // nullable
+    const int32_t* kept;     // nullable
+    const int32_t* n_kept;   // valid iff kept != nullptr
+    float* stats;
+    uint8_t* sel_flag;
+    int64_t stride;          // total_rows
+    int D, C, Ce, NT;
+    int tpw;                 // 16-row tiles per wave (1 when NT > 1)
+};
+
+// one lane per row: reads the 16 x Ctp tile the wave just wrote, emits the statistics
+__device__ __forceinline__ void row_epilogue(const ScoresArgs& a, const float* tile, int ldt,
+                                             int64_t slot_base, int slot, bool valid) {
+    if (!valid) return;
+    const int C = a.C, Ce = a.Ce;
+    const float* r = tile;
+    float m1 = -INFINITY, m2 = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+        const float v = r[c];
+        if (v > m1) { m2 = m1; m1 = v; } else if (v > m2) { m2 = v; }
+    }
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(r[c] - m1);
+    float bsum = 0.f, bmax = -INFINITY;
+    for (int c = C; c < Ce; ++c) { const float v = r[c]; bsum += v; bmax = fmaxf(bmax, v); }
+    float* s = a.stats + slot_base + slot;
+    for (int c = 0; c < C; ++c) {
+        const float v = r[c];
+        s[(int64_t)c * a.stride] = v;
+        s[(int64_t)(C + c) * a.stride] = expf(v - m1) / den;
+    }
+    s[(int64_t)(2 * C) * a.stride] = fabsf(m1 - m2);
+    s[(int64_t)(2 * C + 1) * a.stride] = bsum;
+    s[(int64_t)(2 * C + 2) * a.stride] = bmax;
+    a.sel_flag[slot_base + slot] = 0;
+    (void)ldt;
+}
+
+// CH = elements of K held in registers per chunk (512 or 256).  BF16: bf16 bag.
+template <int CH, bool BF16>
+__global__ __launch_bounds__(256) void scores_kernel(ScoresArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ESZ = BF16 ? 2 : 4;
+    constexpr int NFRAG = CH * ESZ / 64;              // 16-B fragments per lane per chunk
+    const int D = a.D;
+    const int nchunk = D / CH;
+    const int b = blockIdx.y;
+    const int64_t base = a.row_off[b];
+    const int64_t xbase = a.x_off ? a.x_off[b] : base;
+    const int n = (int)(a.row_off[b + 1] - base);
+    const int nk = a.kept ? a.n_kept[b] : n;
+    const int rows_per_wg = 64 * a.tpw;
+    const int wg_row0 = blockIdx.x * rows_per_wg;
+    if (wg_row0 >= nk) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Ctp = a.NT * 16, ldt = Ctp + 1;
+    // LDS: [bank image of one n-tile for all of D][4 waves x 16 x ldt floats]
+    const int img_bytes = BF16 ? (D / 32) * 3 * 1024 : (D / 16) * 1024;
+    uint4* lds_b = reinterpret_cast<uint4*>(smem);
+    float* tile = reinterpret_cast<float*>(smem + img_bytes) + wave * 16 * ldt;
+    const int64_t row_bytes = (int64_t)D * ESZ;
+
+    for (int nt = 0; nt < a.NT; ++nt) {
+        if (nt > 0) __syncthreads();
+        {   // stage this n-tile's bank image
+            const uint4* src = reinterpret_cast<const uint4*>(a.bank + (int64_t)nt * img_bytes);
+            for (int i = threadIdx.x; i < img_bytes / 16; i += 256) lds_b[i] = src[i];
+        }
+        __syncthreads();
+        for (int t = 0; t < a.tpw; ++t) {
+            const int row0 = wg_row0 + (wave * a.tpw + t) * 16;
+            if (row0 >= nk) break;                                  // wave-uniform
+            const int slot = row0 + (lane & 15);
+            const int slot_c = slot < nk ? slot : nk - 1;           // clamp: loads stay in bounds
+            const int r = a.kept ? a.kept[base + slot_c] : slot_c;
+            const unsigned char* rp = a.X + (xbase + r) * row_bytes + (lane >> 4) * 16;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            for (int ch = 0; ch < nchunk; ++ch) {
+                uint4 af[NFRAG];
+#pragma unroll
+                for (int f = 0; f < NFRAG; ++f)
+                    af[f] = *reinterpret_cast<const uint4*>(rp + (int64_t)ch * CH * ESZ + f * 64);
+                if constexpr (BF16) {
+                    const uint4* bp = lds_b + (ch * NFRAG) * 3 * 64 + lane;
+#pragma unroll
+                    for (int f = 0; f < NFRAG; ++f) {
+                        const bf16x8_t A = __builtin_bit_cast(bf16x8_t, af[f]);
+#pragma unroll
+                        for (int term = 0; term < 3; ++term) {
+                            const bf16x8_t Bv = __builtin_bit_cast(bf16x8_t, bp[(f * 3 + term) * 64]);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bv, acc, 0, 0, 0);
+                        }
+                    }
+                } else {
+                    const uint4* bp = lds_b + (ch * NFRAG) * 64 + lane;
+#pragma unroll
+                    for (int f = 0; f < NFRAG; ++f) {
+                        const uint4 bv = bp[f * 64];
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[f].x), __uint_as_float(bv.x), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[f].y), __uint_as_float(bv.y), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[f].z), __uint_as_float(bv.z), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[f].w), __uint_as_float(bv.w), acc, 0, 0, 0);
+                    }
+                }
+            }
+            // C/D layout: acc[i] = out[row (lane>>4)*4 + i][col lane&15]
+            wave_lds_sync();   // previous epilogue reads of this tile are done
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tile[((lane >> 4) * 4 + i) * ldt + nt * 16 + (lane & 15)] = acc[i];
+            wave_lds_sync();
+            if (nt == a.NT - 1 && lane < 16)
+                row_epilogue(a, tile + lane * ldt, ldt, base, row0 + lane, row0 + lane < nk);
+        }
+    }
+}
+
+// Row statistics from a given logits matrix [N, Ct] (row-major): same columns as the score
+// pass writes.  One thread per row; used by the helpers that take logits, not bags.
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* logits, int64_t N, int Ct, int C,
+                                                        float* stats) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float* r = logits + i * Ct;
+    float m1 = -INFINITY, m2 = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+        const float v = r[c];
+        if (v > m1) { m2 = m1; m1 = v; } else if (v > m2) { m2 = v; }
+    }
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(r[c] - m1);
+    float bsum = 0.f, bmax = -INFINITY;
+    for (int c = C; c < Ct; ++c) { const float v = r[c]; bsum += v; bmax = fmaxf(bmax, v); }
+    float* s = stats + i;
+    for (int c = 0; c < C; ++c) {
+        s[(int64_t)c * N] = r[c];
+        s[(int64_t)(C + c) * N] = expf(r[c] - m1) / den;
+    }
+    s[(int64_t)(2 * C) * N] = fabsf(m1 - m2);
+    s[(int64_t)(2 * C + 1) * N] = bsum;
+    s[(int64_t)(2 * C + 2) * N] = bmax;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host entry points
+static int bank_nt(int Ce) { return (Ce + 15) / 16; }
+
+extern "C" size_t moc_bank_bytes(int D, int Ce, int dtype) {
+    if (D <= 0 || Ce <= 0) return 0;
+    const size_t per_nt = dtype == MOC_BF16 ? (size_t)(D / 32) * 3 * 1024 : (size_t)(D / 16) * 1024;
+    return per_nt * bank_nt(Ce);
+}
+
+extern "C" int moc_prepare_bank(const float* W, const float* W_ext, int D, int C, int Ce, int dtype,
+                                int fg_from_ext, void* bank_out, moc_stream_t stream) {
+    MOC_REQUIRE(W && W_ext && bank_out, "moc_prepare_bank: null pointer");
+    MOC_REQUIRE(dtype == MOC_F32 || dtype == MOC_BF16, "moc_prepare_bank: bad dtype %d", dtype);
+    MOC_REQUIRE(C >= 2 && Ce > C, "moc_prepare_bank: need 2 <= C < Ce (logits should have more bg classes), got C=%d Ce=%d", C, Ce);
+    MOC_REQUIRE(D > 0 && D % 256 == 0, "moc_prepare_bank: D=%d must be a multiple of 256", D);
+    hipStream_t s = (hipStream_t)stream;
+    const int NT = bank_nt(Ce);
+    if (dtype == MOC_BF16) {
+        const int total = NT * (D / 32) * 64;
+        prepare_bank_bf16_kernel<<<moc_cdiv(total, 256), 256, 0, s>>>(W, W_ext, D, C, Ce, fg_from_ext, (uint16_t*)bank_out);
+    } else {
+        const int total = NT * (D / 16) * 64;
+        prepare_bank_f32_kernel<<<moc_cdiv(total, 256), 256, 0, s>>>(W, W_ext, D, C, Ce, fg_from_ext, (float*)bank_out);
+    }
+    MOC_CHECK_LAUNCH("moc_prepare_bank");
+    return MOC_OK;
+}
+
+int moc_check_batch(const moc_batch_t* B, const char* who) {
+    MOC_REQUIRE(B, "%s: null batch", who);
+    MOC_REQUIRE(B->X && B->row_off, "%s: null X/row_off", who);
+    MOC_REQUIRE(B->dtype == MOC_F32 || B->dtype == MOC_BF16, "%s: bad dtype %d", who, B->dtype);
+    MOC_REQUIRE(B->D > 0 && B->D % 256 == 0, "%s: D=%d must be a multiple of 256", who, B->D);
+    MOC_REQUIRE(((uintptr_t)B->X & 15) == 0, "%s: X must be 16-byte aligned", who);
+    MOC_REQUIRE(B->n_slides > 0 && B->total_rows > 0 && B->max_rows > 0 && B->max_rows <= B->total_rows,
+                "%s: bad sizes n_slides=%d total_rows=%lld max_rows=%d", who, B->n_slides, (long long)B->total_rows, B->max_rows);
+    MOC_REQUIRE(B->total_rows < (1ll << 31), "%s: total_rows must fit int32", who);
+    MOC_REQUIRE(B->C >= 2 && B->Ce > B->C && B->Ce <= 256, "%s: need 2 <= C < Ce <= 256 (logits should have more bg classes), got C=%d Ce=%d", who, B->C, B->Ce);
+    MOC_REQUIRE(B->topj >= 1 && B->topk >= 1, "%s: topj/topk must be >= 1", who);
+    MOC_REQUIRE(!B->mask || (B->kept && B->n_kept), "%s: mask given but kept/n_kept work arrays are null", who);
+    return MOC_OK;
+}
+
+extern "C" int moc_mask_compact(const moc_batch_t* B, moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_mask_compact")) return rc;
+    if (!B->mask) return MOC_OK;
+    mask_compact_kernel<<<B->n_slides, 1024, 0, (hipStream_t)stream>>>(B->mask, B->row_off, B->kept, B->n_kept);
+    MOC_CHECK_LAUNCH("moc_mask_compact");
+    return MOC_OK;
+}
+
+extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_scores")) return rc;
+    MOC_REQUIRE(bank && B->stats && B->sel_flag, "moc_scores: null bank/stats/sel_flag");
+    ScoresArgs a;
+    a.X = (const unsigned char*)B->X;
+    a.bank = (const unsigned char*)bank;
+    a.row_off = B->row_off;
+    a.x_off = B->x_off;
+    a.kept = B->mask ? B->kept : nullptr;
+    a.n_kept = B->n_kept;
+    a.stats = B->stats;
+    a.sel_flag = B->sel_flag;
+    a.stride = B->total_rows;
+    a.D = B->D; a.C = B->C; a.Ce = B->Ce; a.NT = bank_nt(B->Ce);
+    // rows per workgroup: 256 when the launch is big enough to fill the chip, else 64
+    const int64_t tiles64 = (int64_t)moc_cdiv(B->max_rows, 64) * B->n_slides;
+    a.tpw = (a.NT == 1 && tiles64 >= 4096) ? 4 : 1;
+    const bool bf = B->dtype == MOC_BF16;
+    const size_t img = bf ? (size_t)(B->D / 32) * 3 * 1024 : (size_t)(B->D / 16) * 1024;
+    const size_t smem = img + (size_t)4 * 16 * (a.NT * 16 + 1) * sizeof(float);
+    MOC_REQUIRE(smem <= 160 * 1024, "moc_scores: D=%d needs %zu B of LDS (> 160 KiB)", B->D, smem);
+    dim3 grid(moc_cdiv(B->max_rows, 64 * a.tpw), B->n_slides), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define MOC_LAUNCH_SCORES(CH, BF)                                                                       \
+    do {                                                                                                \
+        static bool attr_set = false;                                                                   \
+        if (!attr_set) {                                                                                \
+            (void)hipFuncSetAttribute((const void*)scores_kernel<CH, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                            \
+        }                                                                                               \
+        scores_kernel<CH, BF><<<grid, block, smem, s>>>(a);                                             \
+    } while (0)
+    if (B->D % 512 == 0) {
+        if (bf) MOC_LAUNCH_SCORES(512, true); else MOC_LAUNCH_SCORES(512, false);
+    } else {
+        if (bf) MOC_LAUNCH_SCORES(256, true); else MOC_LAUNCH_SCORES(256, false);
+    }
+#undef MOC_LAUNCH_SCORES
+    MOC_CHECK_LAUNCH("moc_scores");
+    return MOC_OK;
+}
+
+extern "C" int moc_row_stats(const float* logits, int64_t N, int Ct, int C, float* stats, moc_stream_t stream) {
+    MOC_REQUIRE(logits && stats, "moc_row_stats: null pointer");
+    MOC_REQUIRE(N >= 1 && C >= 1 && Ct >= C, "moc_row_stats: bad shape N=%lld Ct=%d C=%d", (long long)N, Ct, C);
+    row_stats_kernel<<<moc_cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(logits, N, Ct, C, stats);
+    MOC_CHECK_LAUNCH("moc_row_stats");
+    return MOC_OK;
+}

@@ -1,0 +1,342 @@
+// Phase A, part 2: the four top-j patch selectors as column-wise radix selects,
+// their union, the ascending compaction of the union with the candidate scores,
+// and the generic top-K-mean used for pooling.
+//
+// Reference semantics:
+//   psi_p / psi_sigma / psi_delta / psi_beta ... utils/patch_selection_classifier_index.py:17-87
+//   union, sorted ............................. main_moc.py:341-354
+//   candidate scores .......................... main_moc.py:359-366
+//   top-K mean pooling ........................ utils/patch_selection_classifier.py:18-32
+//
+// As *sets* the selectors are 2C+2 independent "j best rows of one key column"
+// problems (psi_delta's C columns are identical, psi_beta is the j smallest
+// background sums: its second topk only permutes them).  Each is one workgroup:
+// a 4-pass 8-bit radix select over order-preserving uint32 keys finds the j-th
+// key exactly; rows above it are marked, ties at it are taken in ascending row
+// order.  Marks from all columns land in one byte-per-row flag array = the union.
+#include "moc_common.h"
+
+int moc_check_batch(const moc_batch_t* B, const char* who);
+
+namespace {
+
+// ---- block-wide radix select -------------------------------------------------
+// Finds T = the `want`-th largest key among n keys produced by keyfn(i), i in [0,n).
+// Returns T and *n_tie_take = how many keys equal to T belong to the top `want`,
+// *n_tie_all = how many keys equal T.  1 <= want <= n.  All threads must call.
+// hist: LDS int[256 + 4].
+template <typename KeyFn>
+__device__ __forceinline__ uint32_t block_radix_select(KeyFn keyfn, int n, int want, int* hist,
+                                                       int* n_tie_take, int* n_tie_all) {
+    uint32_t prefix = 0, pmask = 0;
+    int remaining = want;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t u = keyfn(i);
+            if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            // lane L owns digits 4L..4L+3; inclusive suffix sums over lanes via shuffles
+            const int L = threadIdx.x;
+            const int h0 = hist[4 * L], h1 = hist[4 * L + 1], h2 = hist[4 * L + 2], h3 = hist[4 * L + 3];
+            int suf = h0 + h1 + h2 + h3;   // becomes sum over lanes >= L
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_down(suf, off, 64);
+                if (L + off < 64) suf += o;
+            }
+            const int above = suf - (h0 + h1 + h2 + h3);   // keys in digits > 4L+3
+            // the digit d holding the `remaining`-th key: above(d) < remaining <= above(d) + hist[d]
+            int a3 = above, a2 = above + h3, a1 = a2 + h2, a0 = a1 + h1;
+            int d = -1, ab = 0, hd = 0;
+            if (a3 < remaining && remaining <= a3 + h3) { d = 4 * L + 3; ab = a3; hd = h3; }
+            else if (a2 < remaining && remaining <= a2 + h2) { d = 4 * L + 2; ab = a2; hd = h2; }
+            else if (a1 < remaining && remaining <= a1 + h1) { d = 4 * L + 1; ab = a1; hd = h1; }
+            else if (a0 < remaining && remaining <= a0 + h0) { d = 4 * L; ab = a0; hd = h0; }
+            if (d >= 0) { hist[256] = d; hist[257] = ab; hist[258] = hd; }
+        }
+        __syncthreads();
+        const int d = hist[256];
+        remaining -= hist[257];
+        *n_tie_all = hist[258];
+        prefix |= (uint32_t)d << shift;
+        pmask |= 255u << shift;
+        __syncthreads();
+    }
+    *n_tie_take = remaining;
+    return prefix;
+}
+
+struct SelectArgs {
+    const float* stats;
+    const int64_t* row_off;
+    const int32_t* n_kept;   // nullable (no mask)
+    uint8_t* sel_flag;
+    int64_t stride;
+    int C, topj;
+    uint32_t discard_bits;
+};
+
+// grid (2C+2, n_slides)
+__global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
+    __shared__ int hist[260];
+    __shared__ int wave_tot[17];
+    const int kc = blockIdx.x, b = blockIdx.y, C = a.C;
+    const int sel = kc < C ? 0 : kc < 2 * C ? 1 : kc == 2 * C ? 2 : 3;
+    if (a.discard_bits >> sel & 1u) return;
+    const int64_t base = a.row_off[b];
+    const int nk = a.n_kept ? a.n_kept[b] : (int)(a.row_off[b + 1] - base);
+    if (nk <= 0) return;
+    uint8_t* flag = a.sel_flag + base;
+    if (a.topj >= nk) {   // maxj = min(topj, N'): every kept row is selected
+        for (int i = threadIdx.x; i < nk; i += blockDim.x) flag[i] = 1;
+        return;
+    }
+    // psi_beta ranks by the SMALLEST background sum: invert the key order
+    const float* col = a.stats + (int64_t)(sel == 3 ? 2 * C + 1 : kc) * a.stride + base;
+    const uint32_t flip = sel == 3 ? 0xFFFFFFFFu : 0u;
+    auto keyfn = [&](int i) { return moc_key_desc(col[i]) ^ flip; };
+    int take, ties;
+    const uint32_t T = block_radix_select(keyfn, nk, a.topj, hist, &take, &ties);
+    if (take == ties) {
+        for (int i = threadIdx.x; i < nk; i += blockDim.x)
+            if (keyfn(i) >= T) flag[i] = 1;
+        return;
+    }
+    // more keys tie at the boundary than fit: take the lowest rows first
+    int running = 0;
+    for (int c0 = 0; c0 < nk; c0 += blockDim.x) {
+        const int i = c0 + threadIdx.x;
+        const uint32_t u = i < nk ? keyfn(i) : 0u;
+        const bool tie = i < nk && u == T;
+        int tot;
+        const int pos = moc_block_flag_scan(tie, wave_tot, &tot);
+        if (i < nk && (u > T || (tie && running + pos < take))) flag[i] = 1;
+        running += tot;
+    }
+}
+
+struct CompactArgs {
+    const float* stats;
+    const int64_t* row_off;
+    const int64_t* x_off;    // nullable
+    const int32_t* kept;     // nullable
+    const int32_t* n_kept;   // nullable
+    const uint8_t* sel_flag;
+    int32_t* sel_idx;
+    int64_t* sel_row;
+    int32_t* n_sel;
+    float* cand;
+    const unsigned char* X;
+    unsigned char* selected_feat;   // nullable
+    int64_t stride;
+    int C, row_bytes;
+};
+
+// grid (n_slides)
+__global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a) {
+    __shared__ int wave_tot[17];
+    const int b = blockIdx.x, C = a.C;
+    const int64_t base = a.row_off[b];
+    const int64_t xbase = a.x_off ? a.x_off[b] : base;
+    const int nk = a.n_kept ? a.n_kept[b] : (int)(a.row_off[b + 1] - base);
+    int running = 0;
+    for (int c0 = 0; c0 < nk; c0 += blockDim.x) {
+        const int i = c0 + threadIdx.x;
+        const bool f = i < nk && a.sel_flag[base + i] != 0;
+        int tot;
+        const int pos = moc_block_flag_scan(f, wave_tot, &tot);
+        if (f) {
+            const int64_t o = base + running + pos;
+            a.sel_idx[o] = i;
+            a.sel_row[o] = xbase + (a.kept ? a.kept[base + i] : i);
+            const float* s = a.stats + base + i;
+            float* c = a.cand + o;
+            for (int k = 0; k < 2 * C + 1; ++k) c[(int64_t)k * a.stride] = s[(int64_t)k * a.stride];
+            c[(int64_t)(2 * C + 1) * a.stride] = s[(int64_t)(2 * C + 2) * a.stride];   // s_beta = max background
+        }
+        running += tot;
+    }
+    if (threadIdx.x == 0) a.n_sel[b] = running;
+}
+
+// grid (ceil(max_rows/16), n_slides): copies selected rows (16 B per thread per step)
+__global__ __launch_bounds__(256) void gather_rows_kernel(CompactArgs a) {
+    const int b = blockIdx.y;
+    const int64_t base = a.row_off[b];
+    const int S = a.n_sel[b];
+    const int vec_per_row = a.row_bytes / 16;
+    for (int s = blockIdx.x * 16 + (threadIdx.x >> 4); s < S; s += gridDim.x * 16) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.X + a.sel_row[base + s] * (int64_t)a.row_bytes);
+        uint4* dst = reinterpret_cast<uint4*>(a.selected_feat + (base + s) * (int64_t)a.row_bytes);
+        for (int v = threadIdx.x & 15; v < vec_per_row; v += 16) dst[v] = src[v];
+    }
+}
+
+// ---- generic top-K mean ------------------------------------------------------
+struct TopkArgs {
+    const float* keys;
+    const float* vals;
+    const int64_t* seg_off;
+    const int32_t* seg_len;   // nullable
+    float* pooled;
+    int32_t* idx_out;         // nullable
+    int32_t* cnt_out;         // nullable
+    int64_t key_stride, val_stride;
+    int C, K, smallest, seg0;
+};
+
+// grid (C, n_seg).  All LDS is dynamic (16-B aligned base): [P x u64 list][P x f32 vals][scratch ints],
+// P = K rounded up to a power of two.
+__global__ __launch_bounds__(256) void topk_mean_kernel(TopkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int Pmax = 1;
+    while (Pmax < a.K) Pmax <<= 1;
+    float* lvals = reinterpret_cast<float*>(smem + (size_t)Pmax * 8);
+    int* hist = reinterpret_cast<int*>(smem + (size_t)Pmax * 12);   // [260]
+    int* wave_tot = hist + 260;                                     // [8]
+    int& n_list = hist[268];
+    const int c = blockIdx.x, seg = a.seg0 + blockIdx.y;
+    const int64_t base = a.seg_off[seg];
+    const int n = a.seg_len ? a.seg_len[seg] : (int)(a.seg_off[seg + 1] - base);
+    const int out = seg * a.C + c;
+    if (n <= 0) {   // mean over an empty set: NaN, like torch
+        if (threadIdx.x == 0) {
+            a.pooled[out] = __uint_as_float(0x7FC00000u);
+            if (a.cnt_out) a.cnt_out[out] = 0;
+        }
+        return;
+    }
+    const float* kcol = a.keys + (int64_t)c * a.key_stride + base;
+    const float* vcol = a.vals + (int64_t)c * a.val_stride + base;
+    const uint32_t flip = a.smallest ? 0xFFFFFFFFu : 0u;
+    auto keyfn = [&](int i) { return moc_key_desc(kcol[i]) ^ flip; };
+    const int k = a.K < n ? a.K : n;
+    int P = 1;
+    while (P < k) P <<= 1;
+    unsigned long long* list = reinterpret_cast<unsigned long long*>(smem);   // (key << 32) | ~row : descending
+    if (threadIdx.x == 0) n_list = 0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) list[i] = 0ull;
+    int take = 0, ties = 0;
+    uint32_t T = 0;
+    if (k < n) T = block_radix_select(keyfn, n, k, hist, &take, &ties);
+    else __syncthreads();
+    if (k == n || take == ties) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t u = keyfn(i);
+            if (k == n || u >= T) list[atomicAdd(&n_list, 1)] = ((unsigned long long)u << 32) | (uint32_t)(~(uint32_t)i);
+        }
+    } else {
+        int running = 0;
+        for (int c0 = 0; c0 < n; c0 += blockDim.x) {
+            const int i = c0 + threadIdx.x;
+            const uint32_t u = i < n ? keyfn(i) : 0u;
+            const bool tie = i < n && u == T;
+            int tot;
+            const int pos = moc_block_flag_scan(tie, wave_tot, &tot);
+            if (i < n && (u > T || (tie && running + pos < take)))
+                list[atomicAdd(&n_list, 1)] = ((unsigned long long)u << 32) | (uint32_t)(~(uint32_t)i);
+            running += tot;
+        }
+    }
+    __syncthreads();
+    // bitonic sort, descending (key desc, then row asc); padding zeros sink to the end
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int st = size >> 1; st > 0; st >>= 1) {
+            for (int i = threadIdx.x; i < P; i += blockDim.x) {
+                const int jx = i ^ st;
+                if (jx > i) {
+                    const unsigned long long x = list[i], y = list[jx];
+                    const bool desc = (i & size) == 0;
+                    if (desc ? x < y : x > y) { list[i] = y; list[jx] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (a.idx_out)
+        for (int i = threadIdx.x; i < a.K; i += blockDim.x)
+            a.idx_out[(int64_t)out * a.K + i] = i < k ? (int32_t)(~(uint32_t)(list[i] & 0xFFFFFFFFull)) : -1;
+    // mean of the k values: gather in rank order, fixed-shape pairwise tree (deterministic)
+    for (int i = threadIdx.x; i < P; i += blockDim.x)
+        lvals[i] = i < k ? vcol[(int)(~(uint32_t)(list[i] & 0xFFFFFFFFull))] : 0.f;
+    __syncthreads();
+    if (k <= 64) {
+        if (threadIdx.x == 0) {   // short lists: sequential, largest first (as a [k]-row mean would)
+            float s = 0.f;
+            for (int i = 0; i < k; ++i) s += lvals[i];
+            a.pooled[out] = s / (float)k;
+        }
+    } else {
+        for (int st = P >> 1; st > 0; st >>= 1) {
+            for (int i = threadIdx.x; i < st; i += blockDim.x) lvals[i] += lvals[i + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.pooled[out] = lvals[0] / (float)k;
+    }
+    if (threadIdx.x == 0 && a.cnt_out) a.cnt_out[out] = k;
+}
+
+}  // namespace
+
+extern "C" int moc_select(const moc_batch_t* B, moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_select")) return rc;
+    MOC_REQUIRE(B->stats && B->sel_flag, "moc_select: null stats/sel_flag");
+    SelectArgs a;
+    a.stats = B->stats; a.row_off = B->row_off; a.n_kept = B->mask ? B->n_kept : nullptr;
+    a.sel_flag = B->sel_flag; a.stride = B->total_rows; a.C = B->C; a.topj = B->topj;
+    a.discard_bits = B->discard_bits;
+    dim3 grid(2 * B->C + 2, B->n_slides);
+    select_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(a);
+    MOC_CHECK_LAUNCH("moc_select");
+    return MOC_OK;
+}
+
+extern "C" int moc_gather_candidates(const moc_batch_t* B, void* selected_feat, moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_gather_candidates")) return rc;
+    MOC_REQUIRE(B->stats && B->sel_flag && B->sel_idx && B->sel_row && B->n_sel && B->cand,
+                "moc_gather_candidates: null work array");
+    CompactArgs a;
+    a.stats = B->stats; a.row_off = B->row_off; a.x_off = B->x_off;
+    a.kept = B->mask ? B->kept : nullptr; a.n_kept = B->mask ? B->n_kept : nullptr;
+    a.sel_flag = B->sel_flag; a.sel_idx = B->sel_idx; a.sel_row = B->sel_row; a.n_sel = B->n_sel;
+    a.cand = B->cand; a.X = (const unsigned char*)B->X; a.selected_feat = (unsigned char*)selected_feat;
+    a.stride = B->total_rows; a.C = B->C; a.row_bytes = B->D * moc_elem_size(B->dtype);
+    hipStream_t s = (hipStream_t)stream;
+    compact_kernel<<<B->n_slides, 1024, 0, s>>>(a);
+    MOC_CHECK_LAUNCH("moc_gather_candidates(compact)");
+    if (selected_feat) {
+        int gx = moc_cdiv(B->max_rows, 16);
+        if (gx > 4096) gx = 4096;
+        gather_rows_kernel<<<dim3(gx, B->n_slides), 256, 0, s>>>(a);
+        MOC_CHECK_LAUNCH("moc_gather_candidates(gather)");
+    }
+    return MOC_OK;
+}
+
+int moc_launch_topk_mean(const float* keys, int64_t key_stride, const float* vals, int64_t val_stride,
+                         const int64_t* seg_off, const int32_t* seg_len, int seg0, int n_seg, int C, int K,
+                         int smallest, float* pooled, int32_t* idx_out, int32_t* cnt_out, hipStream_t s) {
+    MOC_REQUIRE(keys && vals && seg_off && pooled, "moc_topk_mean: null pointer");
+    MOC_REQUIRE(n_seg >= 1 && C >= 1, "moc_topk_mean: bad n_seg=%d C=%d", n_seg, C);
+    MOC_REQUIRE(K >= 1 && K <= 4096, "moc_topk_mean: K=%d outside [1, 4096]", K);
+    TopkArgs a;
+    a.keys = keys; a.vals = vals; a.seg_off = seg_off; a.seg_len = seg_len; a.pooled = pooled;
+    a.idx_out = idx_out; a.cnt_out = cnt_out; a.key_stride = key_stride; a.val_stride = val_stride;
+    a.C = C; a.K = K; a.smallest = smallest; a.seg0 = seg0;
+    int P = 1;
+    while (P < K) P <<= 1;
+    topk_mean_kernel<<<dim3(C, n_seg), 256, (size_t)P * 12 + 272 * sizeof(int), s>>>(a);
+    MOC_CHECK_LAUNCH("moc_topk_mean");
+    return MOC_OK;
+}
+
+extern "C" int moc_topk_mean(const float* keys, int64_t key_stride, const float* vals, int64_t val_stride,
+                             const int64_t* seg_off, const int32_t* seg_len, int n_seg, int C, int K,
+                             int smallest, float* pooled, int32_t* idx_out, int32_t* cnt_out,
+                             moc_stream_t stream) {
+    return moc_launch_topk_mean(keys, key_stride, vals, val_stride, seg_off, seg_len, 0, n_seg, C, K, smallest,
+                                pooled, idx_out, cnt_out, (hipStream_t)stream);
+}

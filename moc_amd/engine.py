@@ -1,0 +1,273 @@
+"""Host orchestration over libmoc_hip: packed slide batches, the prepared
+classifier bank, the meta-learner state shared with torch.optim.Adam, and the
+batched phase-A / phase-B drivers.  PyTorch here is plumbing only: it owns the
+device buffers and the stream; every kernel is ours.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import torch
+
+from . import _lib
+from ._lib import MocBatch, MocMeta, MocMetaWs, check, lib, ptr
+
+HIDDEN = 64
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return _lib.MOC_F32
+    if dt == torch.bfloat16:
+        return _lib.MOC_BF16
+    raise AssertionError(f"bag dtype {dt} unsupported (float32 or bfloat16)")
+
+
+class Bank:
+    """The classifier bank [zeroshot_weights | zeroshot_weights_ext[:, C:]] re-laid
+    for the score kernel (moc_prepare_bank).  Cached per (tensors, versions, dtype)."""
+
+    _cache: dict = {}
+
+    def __init__(self, W: torch.Tensor, W_ext: torch.Tensor, dtype: torch.dtype, device, fg_from_ext=False):
+        assert W.dim() == 2 and W_ext.dim() == 2 and W.size(0) == W_ext.size(0)
+        assert W_ext.size(1) > W.size(1), "logits should have more bg classes"
+        self.D, self.C, self.Ce = W.size(0), W.size(1), W_ext.size(1)
+        self.dtype = dtype
+        Wd = W.detach().to(device=device, dtype=torch.float32).contiguous()
+        Wed = W_ext.detach().to(device=device, dtype=torch.float32).contiguous()
+        code = _dtype_code(dtype)
+        nbytes = lib().moc_bank_bytes(self.D, self.Ce, code)
+        self.image = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        check(lib().moc_prepare_bank(ptr(Wd), ptr(Wed), self.D, self.C, self.Ce, code, int(fg_from_ext),
+                                     ptr(self.image), _stream()), "moc_prepare_bank")
+        self._keep = (Wd, Wed)
+
+    @classmethod
+    def get(cls, W, W_ext, dtype, device, fg_from_ext=False) -> "Bank":
+        device = torch.device(device)
+        key = (W.data_ptr(), W._version, tuple(W.shape), W_ext.data_ptr(), W_ext._version,
+               tuple(W_ext.shape), dtype, str(device), bool(fg_from_ext))
+        hit = cls._cache.get(key)
+        if hit is None:
+            if len(cls._cache) > 16:
+                cls._cache.clear()
+            hit = cls._cache[key] = (cls(W, W_ext, dtype, device, fg_from_ext), W, W_ext)
+        return hit[0]
+
+
+class SlideBatch:
+    """Slides packed back to back in one device array + every work array of phase A.
+
+    X: [total_rows, D] device tensor (float32 or bfloat16); sizes: rows per slide.
+    mask: optional bool/uint8 [total_rows] keep flags (host or device)."""
+
+    def __init__(self, X: torch.Tensor, sizes: Sequence[int], C_: int, Ce: int, topj: int, topk: int,
+                 discard=(), mask: torch.Tensor | None = None, x_starts: Sequence[int] | None = None):
+        assert X.is_cuda and X.dim() == 2 and X.is_contiguous()
+        sizes = [int(s) for s in sizes]
+        assert len(sizes) > 0 and min(sizes) > 0, "empty slide"
+        if x_starts is None:
+            assert sum(sizes) == X.size(0), "sizes must partition X's rows"
+        else:
+            assert len(x_starts) == len(sizes) and all(0 <= st and st + n <= X.size(0) for st, n in zip(x_starts, sizes))
+        dev = X.device
+        self.X, self.sizes, self.device = X, sizes, dev
+        self.n_slides, self.total, self.D = len(sizes), sum(sizes), X.size(1)
+        self.C, self.Ce, self.topj, self.topk = int(C_), int(Ce), int(topj), int(topk)
+        self.discard_bits = _lib.discard_bits(discard)
+        off = [0]
+        for s in sizes:
+            off.append(off[-1] + s)
+        self.row_off_host = off
+        self.row_off = torch.tensor(off, dtype=torch.int64).to(dev, non_blocking=True)
+        self.x_off = None
+        if x_starts is not None:
+            self.x_off = torch.tensor([int(v) for v in x_starts], dtype=torch.int64).to(dev, non_blocking=True)
+        T, n = self.total, self.n_slides
+        self.mask = None
+        if mask is not None:
+            assert mask.numel() == T
+            self.mask = mask.to(torch.uint8).to(dev, non_blocking=True).contiguous()
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.kept = torch.empty(T, **i32) if mask is not None else None
+        self.n_kept = torch.empty(n, **i32) if mask is not None else None
+        self.stats = torch.empty((2 * self.C + 3, T), dtype=torch.float32, device=dev)
+        self.sel_flag = torch.empty(T, dtype=torch.uint8, device=dev)
+        self.sel_idx = torch.empty(T, **i32)
+        self.sel_row = torch.empty(T, dtype=torch.int64, device=dev)
+        self.n_sel = torch.empty(n, **i32)
+        self.cand = torch.empty((2 * self.C + 2, T), dtype=torch.float32, device=dev)
+        self.c = MocBatch(
+            X=ptr(X), dtype=_dtype_code(X.dtype), D=self.D, total_rows=T, n_slides=n, max_rows=max(sizes),
+            row_off=ptr(self.row_off), x_off=ptr(self.x_off), mask=ptr(self.mask), C=self.C, Ce=self.Ce, topj=self.topj,
+            topk=self.topk, discard_bits=self.discard_bits, reserved=0, kept=ptr(self.kept),
+            n_kept=ptr(self.n_kept), stats=ptr(self.stats), sel_flag=ptr(self.sel_flag),
+            sel_idx=ptr(self.sel_idx), sel_row=ptr(self.sel_row), n_sel=ptr(self.n_sel), cand=ptr(self.cand))
+        self._ws = None
+
+    # ---- phase A ----
+    def phase_a(self, bank: Bank):
+        assert bank.D == self.D and bank.C == self.C and bank.Ce == self.Ce and bank.dtype == self.X.dtype
+        check(lib().moc_phase_a(C.byref(self.c), ptr(bank.image), _stream()), "moc_phase_a")
+
+    def scores(self, bank: Bank):
+        check(lib().moc_mask_compact(C.byref(self.c), _stream()), "moc_mask_compact")
+        check(lib().moc_scores(C.byref(self.c), ptr(bank.image), _stream()), "moc_scores")
+
+    def select(self):
+        check(lib().moc_select(C.byref(self.c), _stream()), "moc_select")
+
+    def gather_candidates(self, with_feat=False):
+        feat = torch.empty((self.total, self.D), dtype=self.X.dtype, device=self.device) if with_feat else None
+        check(lib().moc_gather_candidates(C.byref(self.c), ptr(feat), _stream()), "moc_gather_candidates")
+        return feat
+
+    # ---- phase B work arrays ----
+    def meta_ws(self):
+        if self._ws is None:
+            dev, T, n, Cc, K = self.device, self.total, self.n_slides, self.C, self.topk
+            f32 = dict(dtype=torch.float32, device=dev)
+            i32 = dict(dtype=torch.int32, device=dev)
+            t = dict(
+                H1=torch.empty((T, HIDDEN), **f32), gates=torch.empty((T, 4), **f32),
+                mixed=torch.empty((Cc, T), **f32), pooled=torch.empty((n, Cc), **f32),
+                topk_idx=torch.empty((n, Cc, K), **i32), topk_cnt=torch.empty((n, Cc), **i32),
+                loss=torch.empty(n, **f32), pred=torch.empty(n, **i32),
+                pair_dh=torch.empty((Cc * K, HIDDEN), **f32),
+                pair_row=torch.empty(Cc * K, dtype=torch.int64, device=dev), n_pair=torch.zeros(1, **i32))
+            self._ws = (t, MocMetaWs(**{k: ptr(v) for k, v in t.items()}))
+        return self._ws
+
+
+class MetaState:
+    """Views of a senet's parameters and its torch.optim.Adam state as the C ABI
+    wants them.  The tensors are the optimizer's own (updated in place), so
+    `optimizer.state_dict()` / `model.state_dict()` stay what the reference saves
+    (main_moc.py:628)."""
+
+    def __init__(self, model, optimizer=None, need_grads=False):
+        lin1, lin2 = model.model[0], model.model[2]
+        self.params = [lin1.weight, lin1.bias, lin2.weight, lin2.bias]
+        assert lin1.out_features == HIDDEN and lin2.out_features == 4 and lin2.in_features == HIDDEN
+        for p in self.params:
+            assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous(), "senet must be fp32 on the GPU"
+        self.D = lin1.in_features
+        self.optimizer = optimizer
+        kw = dict(lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, H=HIDDEN, D=self.D, step=0)
+        names = ("W1", "b1", "W2", "b2")
+        ptrs = {n: ptr(p.data) for n, p in zip(names, self.params)}
+        self.grads = None
+        if optimizer is not None:
+            assert isinstance(optimizer, torch.optim.Adam), "the fused step implements torch.optim.Adam only"
+            groups = [g for g in optimizer.param_groups if any(p is q for p in g["params"] for q in self.params)]
+            assert len(groups) == 1, "senet parameters must sit in one param group"
+            g = groups[0]
+            assert not g.get("amsgrad", False) and not g.get("maximize", False), "amsgrad/maximize unsupported"
+            steps = set()
+            for n, p in zip(names, self.params):
+                st = optimizer.state[p]
+                if len(st) == 0:   # same lazy init as torch.optim.Adam._init_group
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                ptrs["m_" + n], ptrs["v_" + n] = ptr(st["exp_avg"]), ptr(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+            assert len(steps) == 1, "parameters disagree on the Adam step count"
+            b1, b2 = g["betas"]
+            kw.update(lr=float(g["lr"]), beta1=float(b1), beta2=float(b2), eps=float(g["eps"]),
+                      weight_decay=float(g["weight_decay"]), step=steps.pop())
+        if need_grads:
+            self.grads = [torch.zeros_like(p) for p in self.params]
+            for n, gt in zip(names, self.grads):
+                ptrs["g_" + n] = ptr(gt)
+        self.c = MocMeta(**ptrs, **kw)
+
+    def advance(self, n_steps: int):
+        """Record n fused Adam steps in the optimizer's own step counters."""
+        self.c.step += n_steps
+        for p in self.params:
+            st = self.optimizer.state[p]["step"]
+            st += n_steps   # tensor in-place (host or device scalar)
+
+
+def train_use_bits(discard) -> int:
+    return (~_lib.discard_bits(discard)) & 15            # main_moc.py:396-403
+
+
+def eval_use_bits(discard) -> int:
+    """main_moc.py:486-492: psi_p always; the last test is for "delta_bottomk"."""
+    d = discard or ()
+    return 1 | (0 if "delta_softmax" in d else 2) | (0 if "delta_diff" in d else 4) | (0 if "delta_bottomk" in d else 8)
+
+
+def meta_forward(batch: SlideBatch, meta: MetaState, slide0: int, n: int, use_bits: int):
+    _, ws = batch.meta_ws()
+    check(lib().moc_meta_forward(C.byref(batch.c), C.byref(meta.c), C.byref(ws), slide0, n, use_bits, _stream()),
+          "moc_meta_forward")
+
+
+def mix_fixed(batch: SlideBatch, slide0: int, n: int, mode: str):
+    _, ws = batch.meta_ws()
+    code = {"avg": 0, "sum": 1, "max": 2}[mode]
+    check(lib().moc_mix_fixed(C.byref(batch.c), C.byref(ws), slide0, n, code, _stream()), "moc_mix_fixed")
+
+
+def pool_loss(batch: SlideBatch, labels: torch.Tensor, slide0: int, n: int):
+    _, ws = batch.meta_ws()
+    check(lib().moc_pool_loss(C.byref(batch.c), C.byref(ws), ptr(labels), slide0, n, _stream()), "moc_pool_loss")
+
+
+def loss_only(batch: SlideBatch, labels: torch.Tensor, slide0: int, n: int):
+    """CE + argmax of ws.pooled[slide0:slide0+n] (already filled) into ws.loss / ws.pred."""
+    t, _ = batch.meta_ws()
+    check(lib().moc_ce_loss(ptr(t["pooled"][slide0:]), ptr(labels[slide0:]), n, batch.C,
+                            ptr(t["loss"][slide0:]), ptr(t["pred"][slide0:]), _stream()), "moc_ce_loss")
+
+
+def train_steps(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, slide0: int, n: int, use_bits: int):
+    """n consecutive meta-steps (one slide each) with Adam applied in place."""
+    _, ws = batch.meta_ws()
+    check(lib().moc_train_steps(C.byref(batch.c), C.byref(meta.c), C.byref(ws), ptr(labels), slide0, n,
+                                use_bits, _stream()), "moc_train_steps")
+    meta.advance(n)
+
+
+def train_grad(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, slide: int, use_bits: int):
+    """Forward + loss + gradients of one slide into meta.grads (no update)."""
+    _, ws = batch.meta_ws()
+    s = _stream()
+    check(lib().moc_meta_forward(C.byref(batch.c), C.byref(meta.c), C.byref(ws), slide, 1, use_bits, s), "moc_meta_forward")
+    check(lib().moc_pool_loss(C.byref(batch.c), C.byref(ws), ptr(labels), slide, 1, s), "moc_pool_loss")
+    check(lib().moc_train_grad(C.byref(batch.c), C.byref(meta.c), C.byref(ws), ptr(labels), slide, use_bits, s),
+          "moc_train_grad")
+
+
+def adam_step(meta: MetaState, grad_scale: float = 1.0):
+    check(lib().moc_adam_step(C.byref(meta.c), C.c_float(grad_scale), _stream()), "moc_adam_step")
+    meta.advance(1)
+
+
+def topk_mean(keys: torch.Tensor, vals: torch.Tensor, K: int, smallest=False, key_shared=False,
+              want_idx=False, seg_off: torch.Tensor | None = None):
+    """keys/vals: [C, N] device fp32 (keys may be [1, N] with key_shared).  Returns
+    pooled [n_seg, C] (and idx [n_seg, C, K], cnt [n_seg, C])."""
+    assert keys.is_cuda and vals.is_cuda and keys.dtype == vals.dtype == torch.float32
+    keys, vals = keys.contiguous(), vals.contiguous()
+    Cc, N = vals.shape
+    dev = vals.device
+    if seg_off is None:
+        seg_off = torch.tensor([0, N], dtype=torch.int64, device=dev)
+    n_seg = seg_off.numel() - 1
+    pooled = torch.empty((n_seg, Cc), dtype=torch.float32, device=dev)
+    idx = torch.empty((n_seg, Cc, K), dtype=torch.int32, device=dev) if want_idx else None
+    cnt = torch.empty((n_seg, Cc), dtype=torch.int32, device=dev) if want_idx else None
+    check(lib().moc_topk_mean(ptr(keys), 0 if key_shared else N, ptr(vals), N, ptr(seg_off), None, n_seg, Cc,
+                              int(K), int(bool(smallest)), ptr(pooled), ptr(idx), ptr(cnt), _stream()),
+          "moc_topk_mean")
+    return (pooled, idx, cnt) if want_idx else pooled

@@ -1,0 +1,328 @@
+"""Drop-in for the hot-path callables of the reference's main_moc.py
+(senet :299-312, slide_process :322-375, train :378-410, zs_evaluation :412-460,
+evaluation :462-520, ablation_evaluation :523-582): same names, arguments, return
+structures and quirks, computed by libmoc_hip on the MI355X.
+
+Like the reference, train/evaluation read the classifier bank from module
+globals `zeroshot_weights` / `zeroshot_weights_ext` (set them directly or through
+set_classifier_bank).
+
+How the loops map onto the GPU
+  * slide_process has no trainable parameter, so for a whole loader pass its
+    work (mask -> scores -> 4 selectors -> union -> candidates: "phase A") is done
+    for ALL slides in a handful of batched launches before the meta-learner runs;
+  * train then takes one fused Adam step per slide, in loader order, without
+    ever synchronising the host (moc_train_steps); results are those of the
+    reference's sequential loop because phase A does not depend on the parameters;
+  * evaluation / zs_evaluation have no sequential dependence at all and are
+    batched end to end; only the [n_slides, C] pooled logits come back to the
+    host, where sklearn computes the AUC as in the reference.
+  * the row mask is drawn with torch.rand on the CPU default generator, one call
+    per slide in loader order, exactly the stream main_moc.py:330 consumes.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from sklearn.metrics import roc_auc_score
+from tqdm import tqdm
+
+from . import engine
+from .engine import Bank, MetaState, SlideBatch
+from .patch_selection_classifier import (bottomk_irrel_classifier_pooling, delta_diff_classifier_pooling,
+                                         delta_softmax_classifier_pooling, topj_pooling)
+
+zeroshot_weights = None        # [D, C]      main_moc.py:161-202
+zeroshot_weights_ext = None    # [D, C+4]
+
+CONCH_TEMPERATURE = 56.3477    # main_moc.py:443, :505
+# slides are processed in chunks of at most this many bag bytes per phase-A batch
+MAX_BATCH_BYTES = 24 << 30
+
+
+def set_classifier_bank(W: torch.Tensor, W_ext: torch.Tensor):
+    global zeroshot_weights, zeroshot_weights_ext
+    zeroshot_weights, zeroshot_weights_ext = W, W_ext
+
+
+class senet(nn.Module):
+    """The meta-learner; same modules / state_dict keys as main_moc.py:299-312.
+    train()/evaluation() below do not go through forward(): they hand the
+    parameter tensors to the fused kernels."""
+
+    def __init__(self, in_dim, out_dim):
+        super(senet, self).__init__()
+        self.hidden_dim = 64
+        self.model = nn.Sequential(
+            nn.Linear(in_dim, self.hidden_dim),
+            nn.ReLU(),
+            nn.Linear(self.hidden_dim, out_dim),
+            nn.Sigmoid()
+        )
+
+    def forward(self, x):
+        return self.model(x)
+
+
+# --------------------------------------------------------------------------
+def _bag_dtype(args, default):
+    want = getattr(args, "bag_dtype", None)
+    if want in (None, "keep"):
+        return default
+    return {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
+            "bfloat16": torch.bfloat16}[want]
+
+
+def _pack(bags, device, dtype):
+    """list of [N_i, D] tensors -> one contiguous [sum N_i, D] device array."""
+    sizes = [int(b.size(0)) for b in bags]
+    X = torch.empty((sum(sizes), bags[0].size(1)), dtype=dtype, device=device)
+    o = 0
+    for b, n in zip(bags, sizes):
+        X[o:o + n].copy_(b.to(device, non_blocking=True))
+        o += n
+    return X, sizes
+
+
+def _chunks(sizes, D, itemsize):
+    out, cur, cur_bytes = [], [], 0
+    for i, n in enumerate(sizes):
+        nb = n * D * itemsize
+        if cur and cur_bytes + nb > MAX_BATCH_BYTES:
+            out.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(i)
+        cur_bytes += nb
+    if cur:
+        out.append(cur)
+    return out
+
+
+class ResidentBags:
+    """Slides kept packed in HBM across epochs with the
+    loader/dataset protocol main_moc.py's loops use (iteration yields batch_size=1
+    items; .dataset.real_len(), .dataset.repeat_num, len()).  train/evaluation
+    recognise it and skip the per-epoch re-read + host->device copy."""
+
+    def __init__(self, bags, labels, device, dtype=None, repeat_num=None, paths=None):
+        dtype = dtype or bags[0].dtype
+        self.X, self.sizes = _pack(bags, device, dtype)
+        self.labels = [int(v) for v in labels]
+        self.repeat_num = repeat_num
+        self.paths = paths or [f"slide_{i}.h5" for i in range(len(bags))]
+        self.starts = [0]
+        for n in self.sizes:
+            self.starts.append(self.starts[-1] + n)
+        self.dataset = self
+
+    def real_len(self):
+        return len(self.sizes)
+
+    def __len__(self):
+        return self.repeat_num if self.repeat_num else len(self.sizes)
+
+    def visit_order(self):
+        return [i % len(self.sizes) for i in range(len(self))]
+
+    def __iter__(self):
+        for k in self.visit_order():
+            x = self.X[self.starts[k]:self.starts[k + 1]]
+            yield (x.unsqueeze(0), torch.tensor([self.labels[k]]),
+                   torch.zeros(1, x.size(0), 2, dtype=torch.int64), [self.paths[k]])
+
+
+def _collect(loader, device, args):
+    """One pass over a loader -> (X, sizes, x_starts|None, labels)."""
+    if isinstance(loader, ResidentBags):
+        order = loader.visit_order()
+        sizes = [loader.sizes[k] for k in order]
+        return loader.X, sizes, [loader.starts[k] for k in order], [loader.labels[k] for k in order]
+    bags, labels = [], []
+    for data in tqdm(loader, bar_format="{l_bar}{bar:10}{r_bar}", disable=args.disable_tqdm):
+        feats, lbl, coords, full_path = data
+        bags.append(feats.squeeze(0))
+        labels.append(int(lbl.reshape(-1)[0]))
+    dtype = _bag_dtype(args, bags[0].dtype if bags[0].dtype in (torch.float32, torch.bfloat16) else torch.float32)
+    X, sizes = _pack(bags, device, dtype)
+    return X, sizes, None, labels
+
+
+def _sub_batch(X, sizes, x_starts, ids, C_, Ce, topj, topk, discard, masks=None):
+    """SlideBatch over slides `ids` of a collected pass (views, no copies)."""
+    if x_starts is None:
+        starts, o = [], 0
+        for n in sizes:
+            starts.append(o)
+            o += n
+    else:
+        starts = x_starts
+    m = torch.cat([masks[i] for i in ids]) if masks is not None else None
+    return SlideBatch(X, [sizes[i] for i in ids], C_, Ce, topj, topk, discard, mask=m,
+                      x_starts=[starts[i] for i in ids])
+
+
+def _bank_for(X, device, fg_from_ext=False):
+    assert zeroshot_weights is not None and zeroshot_weights_ext is not None, \
+        "set moc_amd.main_moc.zeroshot_weights / zeroshot_weights_ext first (set_classifier_bank)"
+    return Bank.get(zeroshot_weights, zeroshot_weights_ext, X.dtype, device, fg_from_ext)
+
+
+# --------------------------------------------------------------------------
+def slide_process(feat, zeroshot_weights, zeroshot_weights_ext,
+                  n_classes, topj=10, random_mask=False,
+                  discard_classifiers=[]) -> dict:
+    """main_moc.py:322-375.  `selected_index` indexes the MASKED rows, ascending."""
+    device = zeroshot_weights.device
+    if device.type != "cuda":
+        raise RuntimeError("moc_amd.slide_process: the classifier bank must live on the GPU (no CPU fallback)")
+    feat = feat.to(device)
+    if feat.dtype not in (torch.float32, torch.bfloat16):
+        feat = feat.to(torch.float32)
+    feat = feat.contiguous()
+    N = feat.size(0)
+    mask = None
+    if random_mask:
+        mask = torch.rand(N) > 0.5                       # CPU default generator, as the reference
+    C_, Ce = zeroshot_weights.size(1), zeroshot_weights_ext.size(1)
+    assert C_ == n_classes, "n_classes must equal zeroshot_weights.size(1)"
+    batch = SlideBatch(feat, [N], C_, Ce, topj, 1, discard_classifiers, mask=mask)
+    bank = Bank.get(zeroshot_weights, zeroshot_weights_ext, feat.dtype, device)
+    batch.scores(bank)
+    batch.select()
+    sel_feat = batch.gather_candidates(with_feat=True)
+    S = int(batch.n_sel.item())
+    cand = batch.cand[:, :S]
+    return {
+        "selected_index": batch.sel_idx[:S].tolist(),
+        "selected_feat": sel_feat[:S],
+        "logits_top_classifier": cand[:C_].t().contiguous(),
+        "logits_delta_softmax_classifier": cand[C_:2 * C_].t().contiguous(),
+        "logits_delta_diff_classifier": cand[2 * C_].unsqueeze(1).expand(S, C_).contiguous(),
+        "logits_bottomk_irrel_classifier": cand[2 * C_ + 1].unsqueeze(1).expand(S, C_).contiguous(),
+    }
+
+
+def train(model, train_loader, optimizer, device, args):
+    """main_moc.py:378-410: one Adam step per slide, in loader order."""
+    model.train()
+    X, sizes, x_starts, labels = _collect(train_loader, device, args)
+    masks = [torch.rand(n) > 0.5 for n in sizes]          # main_moc.py:330, one draw per slide
+    meta = MetaState(model, optimizer)
+    bank = _bank_for(X, device)
+    C_, Ce = bank.C, bank.Ce
+    assert C_ == args.n_classes
+    use = engine.train_use_bits(args.discard_classifiers)
+    for ids in _chunks(sizes, X.size(1), X.element_size()):
+        batch = _sub_batch(X, sizes, x_starts, ids, C_, Ce, args.topj, args.topk, args.discard_classifiers, masks)
+        lab = torch.tensor([labels[i] for i in ids], dtype=torch.int64).to(device, non_blocking=True)
+        batch.phase_a(bank)
+        engine.train_steps(batch, meta, lab, 0, len(ids), use)
+        train.last = (batch, lab)    # keeps the buffers alive until the stream has drained; also for tests
+
+
+def _metrics(pooled_cpu, labels, losses, n_div, real_len, args):
+    """The shared tail of the three evaluation loops (main_moc.py:439-460, :501-520)."""
+    test_loss = 0
+    for v in losses:
+        test_loss += v
+    test_loss /= n_div
+    lbl_all = torch.tensor(labels, dtype=torch.int64)
+    correct = int((pooled_cpu.argmax(dim=1) == lbl_all).sum().item())
+    if args.pretrain == 'conch':
+        temperature = CONCH_TEMPERATURE
+    else:
+        raise NotImplementedError
+    probs = F.softmax(pooled_cpu * temperature, dim=1)
+    n_classes = probs.shape[1]
+    if n_classes == 2:
+        class_probs = probs[:, 1]
+        roc_kwargs = {}
+    else:
+        class_probs = probs
+        roc_kwargs = {'multi_class': 'ovo', 'average': 'macro'}
+    auc = roc_auc_score(lbl_all.numpy(), class_probs.numpy(), **roc_kwargs)
+    return {"loss": test_loss, "acc": correct / real_len, "auc": auc}
+
+
+def _eval_pass(loader, device, args, mode, model=None, pooling_func=None):
+    X, sizes, x_starts, labels = _collect(loader, device, args)
+    bank = _bank_for(X, device, fg_from_ext=(mode == "zs_bottomk"))
+    C_, Ce = bank.C, bank.Ce
+    meta = MetaState(model) if model is not None else None
+    pooled, losses = [], []
+    for ids in _chunks(sizes, X.size(1), X.element_size()):
+        discard = args.discard_classifiers if mode == "eval" else []
+        batch = _sub_batch(X, sizes, x_starts, ids, C_, Ce, args.topj, args.topk, discard)
+        lab = torch.tensor([labels[i] for i in ids], dtype=torch.int64).to(device, non_blocking=True)
+        n = len(ids)
+        tensors, _ = batch.meta_ws()
+        if mode.startswith("zs"):
+            batch.scores(bank)
+            st, T = batch.stats, batch.total
+            kind = mode[3:]
+            if kind == "topj":
+                keys, vals, small, shared = st[:C_], st[:C_], False, False
+            elif kind == "delta_softmax":
+                keys, vals, small, shared = st[C_:2 * C_], st[:C_], False, False
+            elif kind == "delta_diff":
+                keys, vals, small, shared = st[2 * C_:2 * C_ + 1], st[:C_], False, True
+            else:   # bottomk: K rows of smallest background mass, mean of their foreground logits
+                keys, vals, small, shared = st[2 * C_ + 1:2 * C_ + 2], st[:C_], True, True
+            p = engine.topk_mean(keys, vals, args.topk, smallest=small, key_shared=shared, seg_off=batch.row_off)
+            tensors["pooled"].copy_(p)
+            engine.loss_only(batch, lab, 0, n)
+        else:
+            batch.phase_a(bank)
+            if mode == "eval":
+                engine.meta_forward(batch, meta, 0, n, engine.eval_use_bits(args.discard_classifiers))
+            else:
+                engine.mix_fixed(batch, 0, n, args.ablation_study)
+            engine.pool_loss(batch, lab, 0, n)
+        pooled.append(tensors["pooled"].cpu())
+        losses.extend(tensors["loss"].cpu().tolist())
+    return torch.cat(pooled, 0), labels, losses
+
+
+def zs_evaluation(loader, device, args, pooling_func=topj_pooling):
+    """main_moc.py:412-460."""
+    with torch.no_grad():
+        real_len = loader.dataset.real_len()
+        set_len = loader.dataset.repeat_num
+        loader.dataset.repeat_num = real_len
+        kinds = {topj_pooling: "topj", delta_softmax_classifier_pooling: "delta_softmax",
+                 delta_diff_classifier_pooling: "delta_diff", bottomk_irrel_classifier_pooling: "bottomk"}
+        if pooling_func not in kinds:
+            raise NotImplementedError("zs_evaluation: pooling_func must be one of moc_amd.patch_selection_classifier's four")
+        try:
+            pooled, labels, losses = _eval_pass(loader, device, args, "zs_" + kinds[pooling_func])
+        finally:
+            loader.dataset.repeat_num = set_len
+    return _metrics(pooled, labels, losses, len(loader.dataset), real_len, args)
+
+
+def evaluation(model, loader, device, args):
+    """main_moc.py:462-520 (incl. the eval-side mix quirk, see engine.eval_use_bits)."""
+    model.eval()
+    with torch.no_grad():
+        real_len = loader.dataset.real_len()
+        set_len = len(loader.dataset)
+        loader.dataset.repeat_num = real_len
+        try:
+            pooled, labels, losses = _eval_pass(loader, device, args, "eval", model=model)
+        finally:
+            loader.dataset.repeat_num = set_len
+    return _metrics(pooled, labels, losses, len(loader.dataset), real_len, args)
+
+
+def ablation_evaluation(loader, device, args):
+    """main_moc.py:523-582, args.ablation_study in {avg, sum, max}."""
+    real_len = loader.dataset.real_len()
+    set_len = len(loader.dataset)
+    loader.dataset.repeat_num = real_len
+    try:
+        with torch.no_grad():
+            pooled, labels, losses = _eval_pass(loader, device, args, "ablation")
+    finally:
+        loader.dataset.repeat_num = set_len
+    return _metrics(pooled, labels, losses, len(loader.dataset), real_len, args)

@@ -1,0 +1,459 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and with the golden
+fixtures the reference produced.  Needs an MI355X: run with -m gpu.
+
+Tolerances: north_star states 1e-4 fp32 for outputs; index work is compared as
+sets, exact except rows whose key lies within helpers.KEY_BAND of a top-j
+boundary (fp32 dot products summed in a different order than MKL's differ by
+~1e-7, which may swap the rows ranked j and j+1)."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from moc_amd import synth
+from oracle import moc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ATOL = H.ATOL
+TIGHT = 2e-6      # fp32 re-association noise on O(1) cosine logits
+
+
+@pytest.fixture(scope="module")
+def dev(gpu_device):
+    return gpu_device
+
+
+def _mm():
+    from moc_amd import main_moc
+    return main_moc
+
+
+def _engine():
+    from moc_amd import engine
+    return engine
+
+
+# ------------------------------------------------------------------ score pass
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,D", [(1, 2, 512), (17, 2, 512), (1000, 3, 512), (4099, 30, 512), (700, 64, 1024), (333, 2, 256)])
+def test_scores_and_row_stats_match_oracle(dev, dtype, N, C, D):
+    E = _engine()
+    W, We = synth.make_bank(100 + N, D, C)
+    x = synth.make_bag(200 + N, N, D, We, C, label=0)
+    xs = x.to(dtype)                     # storage rounding is part of the INPUT
+    xr = xs.to(torch.float32)
+    batch = E.SlideBatch(xs.to(dev).contiguous(), [N], C, C + 4, 10, 10)
+    batch.scores(E.Bank.get(W, We, dtype, dev))
+    st = batch.stats.cpu()
+    lg, lge = xr @ W, xr @ We
+    keys = H.selector_keys(lge, C)
+    np.testing.assert_allclose(st[:C].t().numpy(), lg.numpy(), atol=TIGHT, rtol=0)
+    np.testing.assert_allclose(st[C:2 * C].t().numpy(), keys["softmax"].numpy(), atol=TIGHT, rtol=0)
+    np.testing.assert_allclose(st[2 * C].numpy(), keys["gap"][:, 0].numpy(), atol=2 * TIGHT, rtol=0)
+    np.testing.assert_allclose(st[2 * C + 1].numpy(), lge[:, C:].sum(1).numpy(), atol=4 * TIGHT, rtol=0)
+    np.testing.assert_allclose(st[2 * C + 2].numpy(), lge[:, C:].max(1)[0].numpy(), atol=TIGHT, rtol=0)
+    assert int(batch.sel_flag.sum()) == 0
+
+
+def test_scores_uses_W_for_foreground_and_Wext_for_background(dev):
+    """main_moc.py:336-337: logits come from W, only the background from W_ext."""
+    E = _engine()
+    W, We = synth.make_bank(5, 512, 2)
+    We = We.clone()
+    We[:, :2] = torch.flip(We[:, :2], dims=[1]) * 0.5          # make W_ext[:, :C] != W
+    x = synth.make_bag(6, 300, 512, We, 2, label=1)
+    batch = E.SlideBatch(x.to(dev), [300], 2, 6, 10, 10)
+    batch.scores(E.Bank.get(W, We, torch.float32, dev))
+    np.testing.assert_allclose(batch.stats[:2].t().cpu().numpy(), (x @ W).numpy(), atol=TIGHT)
+    batch.scores(E.Bank.get(W, We, torch.float32, dev, fg_from_ext=True))
+    np.testing.assert_allclose(batch.stats[:2].t().cpu().numpy(), (x @ We[:, :2]).numpy(), atol=TIGHT)
+
+
+# ------------------------------------------------------------------ selection: exact on identical keys
+def _stats_from_logits_ext(lge, C):
+    k = H.selector_keys(lge, C)
+    return torch.cat([lge[:, :C].t(), k["softmax"].t(), k["gap"].t(), lge[:, C:].sum(1, keepdim=True).t(),
+                      lge[:, C:].max(1, keepdim=True)[0].t()], 0).contiguous()
+
+
+def test_select_union_is_exact_on_reference_keys(dev):
+    """Feed the selectors the reference's own logits: the union must equal the union of the
+    reference's four index tensors bit for bit (integer/index work)."""
+    E = _engine()
+    g = H.golden("selectors")
+    for cid, N, C, j, seed in g["cases"]:
+        lge = torch.from_numpy(g[f"c{cid}_logits_ext"])
+        x = torch.zeros(int(N), 256)
+        for dbits in (0, 1, 2, 4, 8, 5, 14):
+            discard = H.discard_from_mask(dbits)
+            batch = E.SlideBatch(x.to(dev), [int(N)], int(C), int(C) + 4, int(j), 10, discard)
+            batch.stats.copy_(_stats_from_logits_ext(lge, int(C)))
+            batch.sel_flag.zero_()
+            batch.select()
+            batch.gather_candidates()
+            S = int(batch.n_sel.item())
+            got = batch.sel_idx[:S].cpu().tolist()
+            exp = set()
+            for name, sel in (("top", "topk"), ("softmax", "delta_softmax"), ("gap", "delta_diff"), ("lowbg", "bottomk")):
+                if sel not in discard:
+                    exp.update(g[f"c{cid}_{name}"].flatten().tolist())
+            if got != sorted(exp):
+                # the softmax keys are recomputed by this host's libm: a last-ulp difference from
+                # the host that wrote the fixture may swap two rows AT the boundary, nothing else
+                keys = H.selector_keys(lge, int(C))
+                amb = H.ambiguous_rows(keys, int(j), band=3e-7)
+                assert (set(got) ^ exp) <= amb, f"case {cid} discard {discard}: {sorted((set(got) ^ exp) - amb)[:8]}"
+            assert got == sorted(got) and len(set(got)) == len(got)
+            assert np.array_equal(batch.sel_row[:S].cpu().numpy(), np.asarray(got))
+
+
+def test_select_ties_take_lowest_rows(dev):
+    E = _engine()
+    N, C = 3000, 2
+    lge = torch.zeros(N, C + 4)
+    lge[:, 0] = torch.arange(N).float() % 7          # heavy ties
+    lge[:, 1] = -lge[:, 0]
+    lge[:, 2:] = 1.0
+    batch = E.SlideBatch(torch.zeros(N, 256, device=dev), [N], C, C + 4, 500, 10, ["delta_softmax", "delta_diff", "bottomk"])
+    batch.stats.copy_(_stats_from_logits_ext(lge, C))
+    batch.sel_flag.zero_()
+    batch.select()
+    batch.gather_candidates()
+    got = set(batch.sel_idx[: int(batch.n_sel.item())].cpu().tolist())
+    exp = set()
+    for c in range(C):
+        col = lge[:, c]
+        order = sorted(range(N), key=lambda i: (-float(col[i]), i))[:500]
+        exp.update(order)
+    assert got == exp
+
+
+# ------------------------------------------------------------------ slide_process vs the reference fixtures
+def _check_slide_process(dev, r, x_kept, W, We, C, j, discard, exp_idx, exp_cands, band=H.KEY_BAND):
+    lge = x_kept @ We
+    lge = torch.cat([x_kept @ W, lge[:, C:]], 1)
+    keys = H.selector_keys(lge, C)
+    amb = H.ambiguous_rows({k: v for k, v in keys.items()
+                            if {"top": "topk", "softmax": "delta_softmax", "gap": "delta_diff", "lowbg": "bottomk"}[k] not in discard},
+                           j, band)
+    got, exp = set(r["selected_index"]), set(int(i) for i in exp_idx)
+    assert r["selected_index"] == sorted(got)
+    assert (got ^ exp) <= amb, f"selected_index differs outside the tie band: {sorted((got ^ exp) - amb)[:10]}"
+    pos_g = {v: i for i, v in enumerate(r["selected_index"])}
+    pos_e = {int(v): i for i, v in enumerate(exp_idx)}
+    common = sorted(got & exp)
+    ig, ie = [pos_g[v] for v in common], [pos_e[v] for v in common]
+    assert torch.equal(r["selected_feat"].cpu(), x_kept[r["selected_index"]])
+    for key, name in (("logits_top_classifier", "top"), ("logits_delta_softmax_classifier", "softmax"),
+                      ("logits_delta_diff_classifier", "gap"), ("logits_bottomk_irrel_classifier", "lowbg")):
+        assert tuple(r[key].shape) == (len(got), C)
+        np.testing.assert_allclose(r[key].cpu().numpy()[ig], exp_cands[name][ie], atol=1e-5, rtol=0)
+
+
+def test_slide_process_matches_reference_fixtures(dev):
+    M = _mm()
+    g = H.golden("slide_process")
+    for cid, N, C, j, rm, dmask, seed in g["cases"]:
+        W, We, x = H.bank_and_bag(seed, N, C, cid % C)
+        mask = H.unpack_mask(g[f"c{cid}_mask"], N)
+        discard = H.discard_from_mask(dmask)
+        torch.manual_seed(int(seed))                       # same CPU stream as the reference run
+        r = M.slide_process(x.to(dev), W.to(dev), We.to(dev), int(C), topj=int(j), random_mask=bool(rm),
+                            discard_classifiers=discard)
+        cands = {n: g[f"c{cid}_{n}"] for n in ("top", "softmax", "gap", "lowbg")}
+        _check_slide_process(dev, r, x[mask], W, We, int(C), int(j), discard, g[f"c{cid}_selected_index"], cands)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_slide_process_full_size_vs_oracle(dev, dtype):
+    """BASELINE config 2 shape: 15k x 512, C=2, topj=400, row mask on."""
+    M = _mm()
+    N, C, j = 15000, 2, 400
+    W, We = synth.make_bank(31, 512, C)
+    x = synth.make_bag(32, N, 512, We, C, label=1).to(dtype)
+    xr = x.to(torch.float32)
+    torch.manual_seed(77)
+    mask = O.draw_mask(N)
+    torch.manual_seed(77)
+    r = M.slide_process(x.to(dev), W.to(dev), We.to(dev), C, topj=j, random_mask=True)
+    ref = O.slide_process(xr, W, We, C, topj=j, mask=mask)
+    cands = {"top": ref["logits_top_classifier"].numpy(), "softmax": ref["logits_delta_softmax_classifier"].numpy(),
+             "gap": ref["logits_delta_diff_classifier"].numpy(), "lowbg": ref["logits_bottomk_irrel_classifier"].numpy()}
+    assert r["selected_feat"].dtype == dtype
+    r = dict(r, selected_feat=r["selected_feat"].to(torch.float32))
+    _check_slide_process(dev, r, xr[mask], W, We, C, j, [], ref["selected_index"], cands)
+
+
+def test_slide_process_edge_cases(dev):
+    M = _mm()
+    W, We = synth.make_bank(3, 512, 2)
+    x = synth.make_bag(4, 5, 512, We, 2, label=0)
+    r = M.slide_process(x.to(dev), W.to(dev), We.to(dev), 2, topj=400)
+    assert r["selected_index"] == [0, 1, 2, 3, 4]                    # N < topj: every row
+    r = M.slide_process(x.to(dev), W.to(dev), We.to(dev), 2, topj=400,
+                        discard_classifiers=["topk", "delta_softmax", "delta_diff", "bottomk"])
+    assert r["selected_index"] == [] and tuple(r["logits_top_classifier"].shape) == (0, 2)
+    with pytest.raises(AssertionError, match="more bg classes"):
+        M.slide_process(x.to(dev), W.to(dev), W.to(dev), 2, topj=4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        M.slide_process(x, W, We, 2)
+
+
+# ------------------------------------------------------------------ pooling / ranking helpers
+def test_pooling_functions_match_reference_fixtures(dev):
+    from moc_amd import patch_selection_classifier as P
+    g = H.golden("pooling")
+    for cid, N, C, seed in g["cases"]:
+        W, We, x = H.bank_and_bag(seed, N, C, 0)
+        lg, lge = (x @ W).to(dev), (x @ We).to(dev)
+        for K in (1, 10):
+            got = {"topj": P.topj_pooling(lg, [K]), "softmax": P.delta_softmax_classifier_pooling(lg, [K]),
+                   "gap": P.delta_diff_classifier_pooling(lg, [K]),
+                   "lowbg": P.bottomk_irrel_classifier_pooling(lge, [K], coords_list=int(C))}
+            for name, (preds, pooled) in got.items():
+                assert tuple(pooled[K].shape) == (1, C) and preds[K].dtype == torch.int64
+                np.testing.assert_allclose(pooled[K].cpu().numpy(), g[f"c{cid}_K{K}_{name}"], atol=1e-5, rtol=0)
+        preds, pooled, idx = P.topj_pooling(lg, [10], return_indices=True)
+        assert np.array_equal(idx.cpu().numpy().astype(np.int32), g[f"c{cid}_topj_idx"])
+        assert np.array_equal(preds[10].cpu().numpy().astype(np.int32), g[f"c{cid}_topj_pred"])
+
+
+def test_index_functions_match_reference_fixtures(dev):
+    from moc_amd import patch_selection_classifier_index as I
+    g = H.golden("selectors")
+    for cid, N, C, j, seed in g["cases"]:
+        if cid % 3:      # a third of the cases is plenty here; the union test covers all
+            continue
+        lge = torch.from_numpy(g[f"c{cid}_logits_ext"])
+        lg = lge[:, :C].contiguous()
+        keys = H.selector_keys(lge, int(C))
+        got = {"top": I.index_topj_classifier(lg.to(dev), [int(j)]),
+               "softmax": I.index_delta_softmax_classifier(lg.to(dev), [int(j)]),
+               "gap": I.index_delta_diff_classifier(lg.to(dev), [int(j)]),
+               "lowbg": I.index_bottomk_irrel_classifier(lge.to(dev), [int(j)], int(C))}
+        for name, idx in got.items():
+            exp = g[f"c{cid}_{name}"]
+            assert idx.dtype == torch.int64 and tuple(idx.shape) == exp.shape
+            idx = idx.cpu()
+            for c in range(int(C)):
+                kc = keys[name][:, c if keys[name].size(1) > 1 else 0]
+                H.assert_topj_set(idx[:, c].tolist(), exp[:, c].tolist(), kc, what=f"c{cid} {name}[{c}]")
+            if name == "top":     # value order: keys non-increasing down each column
+                v = torch.gather(lg, 0, idx)
+                assert bool((v[1:] <= v[:-1]).all())
+
+
+def test_topk_mean_edges(dev):
+    E = _engine()
+    v = torch.tensor([[3.0, 1.0, 2.0, 2.0, 5.0]], device=dev)
+    pooled, idx, cnt = E.topk_mean(v, v, 3, want_idx=True)
+    assert abs(float(pooled[0, 0]) - (5 + 3 + 2) / 3) < 1e-6 and idx[0, 0].tolist() == [4, 0, 2] and int(cnt[0, 0]) == 3
+    pooled, idx, cnt = E.topk_mean(v, v, 10, want_idx=True)          # K > N: mean over all (S < K)
+    assert abs(float(pooled[0, 0]) - 13 / 5) < 1e-6 and int(cnt[0, 0]) == 5 and idx[0, 0].tolist()[:5] == [4, 0, 2, 3, 1]
+    pooled = E.topk_mean(v, v, 2, smallest=True)
+    assert abs(float(pooled[0, 0]) - 1.5) < 1e-6
+    big = torch.randn(3, 50000, device=dev)
+    pooled, idx, _ = E.topk_mean(big, big, 400, want_idx=True)
+    ref = big.cpu().topk(400, dim=1)
+    np.testing.assert_allclose(pooled[0].cpu().numpy(), ref[0].mean(1).numpy(), atol=1e-5)
+    assert torch.equal(idx[0].cpu().long(), ref[1])
+
+
+# ------------------------------------------------------------------ train steps
+def _run_train_case(dev, bags, labels, masks, W, We, C, j, K, discard, model_seed, dtype=torch.float32):
+    M, E = _mm(), _engine()
+    M.set_classifier_bank(W.to(dev), We.to(dev))
+    torch.manual_seed(model_seed)
+    model = M.senet(512, 4).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    X, sizes = M._pack([b.to(dtype) for b in bags], dev, dtype)
+    batch = E.SlideBatch(X, sizes, C, C + 4, j, K, discard, mask=torch.cat(masks))
+    batch.phase_a(E.Bank.get(M.zeroshot_weights, M.zeroshot_weights_ext, dtype, dev))
+    lab = torch.tensor(labels, dtype=torch.int64, device=dev)
+    return M, E, model, opt, batch, lab
+
+
+def test_train_steps_match_reference_fixtures(dev):
+    g = H.golden("train")
+    for cid, ns, N, C, j, K, dmask, seed in g["cases"]:
+        ns, N, C, j, K = int(ns), int(N), int(C), int(j), int(K)
+        W, We = synth.make_bank(seed, 512, C)
+        bags, labels = synth.make_slide_set(seed + 100, [N] * ns, 512, We, C)
+        masks = H.unpack_masks(g[f"c{cid}_masks"], [N] * ns)
+        discard = H.discard_from_mask(dmask)
+        M, E, model, opt, batch, lab = _run_train_case(dev, bags, labels, masks, W, We, C, j, K, discard, int(seed))
+        np.testing.assert_array_equal(H.flat_params(model), g[f"c{cid}_init"])
+        use = E.train_use_bits(discard)
+        # gradients of the first step, without updating
+        meta_g = E.MetaState(model, None, need_grads=True)
+        E.train_grad(batch, meta_g, lab, 0, use)
+        grads = torch.cat([t.reshape(-1) for t in meta_g.grads]).cpu().numpy()
+        np.testing.assert_allclose(grads, g[f"c{cid}_grad1"], atol=2e-6, rtol=1e-4)
+        # then the real thing, one step at a time so state can be compared after step 1 and ns
+        meta = E.MetaState(model, opt)
+        t, _ = batch.meta_ws()
+        for s in range(ns):
+            E.train_steps(batch, meta, lab, s, 1, use)
+            if s in (0, ns - 1):
+                H.assert_adam_params_close(H.flat_params(model), g[f"c{cid}_params_s{s}"], g[f"c{cid}_v_s{s}"],
+                                           step=s + 1, grad_noise=1e-6, what=f"c{cid} step {s}")
+                np.testing.assert_allclose(H.flat_state(opt, "exp_avg"), g[f"c{cid}_m_s{s}"], atol=1e-6 * (s + 1))
+                np.testing.assert_allclose(H.flat_state(opt, "exp_avg_sq"), g[f"c{cid}_v_s{s}"], atol=1e-8)
+        np.testing.assert_allclose(t["loss"].cpu().numpy(), g[f"c{cid}_loss"], atol=ATOL)
+        np.testing.assert_allclose(t["pooled"].cpu().numpy(), g[f"c{cid}_pooled"], atol=ATOL)
+        assert all(int(float(opt.state[p]["step"])) == ns for p in model.parameters())
+
+
+def test_train_function_matches_oracle_epoch(dev):
+    """moc_amd.main_moc.train over a loader == the oracle's sequential loop, same init, same masks
+    (drawn from the same CPU generator state)."""
+    M = _mm()
+    C, j, K, ns, N = 2, 400, 10, 8, 6000
+    W, We = synth.make_bank(41, 512, C)
+    bags, labels = synth.make_slide_set(4100, [N + 37 * i for i in range(ns)], 512, We, C)
+    torch.manual_seed(9)
+    ref_model = O.Senet(512, 4)
+    ref_opt = O.make_optimizer(ref_model)
+    torch.manual_seed(9)
+    model = M.senet(512, 4).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    M.set_classifier_bank(W.to(dev), We.to(dev))
+    args = H.make_args(C, j, K)
+    for epoch in range(2):
+        torch.manual_seed(1000 + epoch)
+        ref_losses = O.train_epoch(ref_model, ref_opt, bags, labels, W, We, C, j, K)
+        torch.manual_seed(1000 + epoch)
+        M.train(model, H.ListLoader(bags, labels), opt, dev, args)
+        batch, _ = M.train.last
+        np.testing.assert_allclose(batch.meta_ws()[0]["loss"].cpu().numpy(), np.asarray(ref_losses), atol=ATOL)
+    H.assert_adam_params_close(H.flat_params(model), H.flat_params(ref_model), H.flat_state(ref_opt, "exp_avg_sq"),
+                               step=2 * ns, grad_noise=1e-6, what="after 2 epochs")
+    ev_ref = O.evaluation(ref_model, bags, labels, W, We, C, j, K)
+    ev = M.evaluation(model, H.ListLoader(bags, labels), dev, args)
+    assert abs(ev["loss"] - ev_ref["loss"]) < ATOL and ev["acc"] == ev_ref["acc"] and abs(ev["auc"] - ev_ref["auc"]) < 2e-3
+
+
+def test_train_on_resident_bags_with_repeats_and_bf16(dev):
+    """repeat_num > real_len revisits slides (dataset_generic.py:380-393), each visit with a fresh
+    mask; bf16 storage is compared with the oracle fed the same bf16-rounded values."""
+    M = _mm()
+    C, j, K = 3, 100, 10
+    W, We = synth.make_bank(51, 512, C)
+    bags, labels = synth.make_slide_set(5100, [900, 1100, 1000], 512, We, C)
+    bags = [b.to(torch.bfloat16) for b in bags]
+    ref_bags = [b.to(torch.float32) for b in bags]
+    order = [0, 1, 2, 0, 1]
+    torch.manual_seed(3)
+    ref_model = O.Senet(512, 4)
+    ref_opt = O.make_optimizer(ref_model)
+    torch.manual_seed(3)
+    model = M.senet(512, 4).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    M.set_classifier_bank(W.to(dev), We.to(dev))
+    res = M.ResidentBags(bags, labels, dev, repeat_num=5)
+    assert len(res) == 5 and res.real_len() == 3 and res.X.dtype == torch.bfloat16
+    torch.manual_seed(123)
+    ref_losses = O.train_epoch(ref_model, ref_opt, [ref_bags[k] for k in order], [labels[k] for k in order],
+                               W, We, C, j, K)
+    torch.manual_seed(123)
+    M.train(model, res, opt, dev, H.make_args(C, j, K))
+    np.testing.assert_allclose(M.train.last[0].meta_ws()[0]["loss"].cpu().numpy(), np.asarray(ref_losses), atol=ATOL)
+    H.assert_adam_params_close(H.flat_params(model), H.flat_params(ref_model), H.flat_state(ref_opt, "exp_avg_sq"),
+                               step=5, grad_noise=1e-6, what="resident bf16")
+    ev = M.evaluation(model, res, dev, H.make_args(C, j, K))
+    assert res.repeat_num == 5                      # restored like main_moc.py:499
+    ev_ref = O.evaluation(ref_model, ref_bags, labels, W, We, C, j, K, len_dataset=5)
+    assert abs(ev["loss"] - ev_ref["loss"]) < ATOL and ev["acc"] == ev_ref["acc"]
+
+
+# ------------------------------------------------------------------ evaluation loops
+def test_evaluations_match_reference_fixtures(dev):
+    M = _mm()
+    from moc_amd import patch_selection_classifier as P
+    g = H.golden("evaluation")
+    for cid, ns, N, C, j, K, dmask, repeat_num, seed in g["cases"]:
+        ns, N, C, j, K = int(ns), int(N), int(C), int(j), int(K)
+        W, We = synth.make_bank(seed, 512, C)
+        bags, labels = synth.make_slide_set(seed + 100, [N] * ns, 512, We, C)
+        torch.manual_seed(int(seed))
+        model = M.senet(512, 4).to(dev)
+        np.testing.assert_array_equal(H.flat_params(model), g[f"c{cid}_init"])
+        M.set_classifier_bank(W.to(dev), We.to(dev))
+        args = H.make_args(C, j, K, H.discard_from_mask(dmask))
+        rn = int(repeat_num) or None
+
+        def close(got, exp, what):
+            assert abs(got["loss"] - exp[0]) < ATOL, (what, got, exp)
+            assert abs(got["acc"] - exp[1]) < 1e-12, (what, got, exp)
+            assert abs(got["auc"] - exp[2]) < 2e-3, (what, got, exp)     # north_star: AUC within +-0.002
+
+        loader = H.ListLoader(bags, labels, rn)
+        close(M.evaluation(model, loader, dev, args), g[f"c{cid}_eval"], "evaluation")
+        assert loader.dataset.repeat_num == (rn or ns)     # evaluation() leaves len(dataset) there (main_moc.py:470,:499)
+        for name, fn in (("topj", P.topj_pooling), ("delta_softmax", P.delta_softmax_classifier_pooling),
+                         ("delta_diff", P.delta_diff_classifier_pooling), ("bottomk", P.bottomk_irrel_classifier_pooling)):
+            loader = H.ListLoader(bags, labels, rn)
+            close(M.zs_evaluation(loader, dev, args, pooling_func=fn), g[f"c{cid}_zs_{name}"], "zs " + name)
+            assert loader.dataset.repeat_num == rn
+        for mode in ("avg", "sum", "max"):
+            args.ablation_study = mode
+            close(M.ablation_evaluation(H.ListLoader(bags, labels, rn), dev, args), g[f"c{cid}_abl_{mode}"], "ablation " + mode)
+
+
+def test_eval_quirk_delta_bottomk_string(dev):
+    """main_moc.py:491 tests for "delta_bottomk": discarding "bottomk" removes psi_beta from the
+    SELECTION but its term still enters the eval mix."""
+    E = _engine()
+    assert E.eval_use_bits(["bottomk"]) == 15 and E.eval_use_bits(["delta_bottomk"]) == 7
+    assert E.eval_use_bits(["topk", "delta_diff"]) == 1 | 2 | 8 and E.train_use_bits(["topk", "delta_diff"]) == 2 | 8
+
+
+# ------------------------------------------------------------------ size-independent properties at full size
+def test_full_size_properties(dev):
+    """32 slides x ~15k rows (BASELINE config 2): row permutation leaves every slide's pooled
+    logits unchanged; batching does not change per-slide results; n_sel respects its bound."""
+    M, E = _mm(), _engine()
+    C, j, K = 2, 400, 10
+    W, We = synth.make_bank(61, 512, C)
+    Wd, Wed = W.to(dev), We.to(dev)
+    sizes = synth.bag_sizes(5, 32, 15000, fixed=False)
+    bags = [synth.make_bag_device(6100 + i, n, 512, We, C, i % C, dev) for i, n in enumerate(sizes)]
+    labels = [i % C for i in range(32)]
+    torch.manual_seed(0)
+    model = M.senet(512, 4).to(dev)
+    M.set_classifier_bank(Wd, Wed)
+    args = H.make_args(C, j, K)
+    X, _ = M._pack(bags, dev, torch.float32)
+    lab = torch.tensor(labels, device=dev)
+    meta = E.MetaState(model)
+
+    def run(Xp, szs):
+        b = E.SlideBatch(Xp, szs, C, C + 4, j, K)
+        b.phase_a(E.Bank.get(Wd, Wed, torch.float32, dev))
+        E.meta_forward(b, meta, 0, len(szs), 15)
+        E.pool_loss(b, lab[: len(szs)], 0, len(szs))
+        return b, b.meta_ws()[0]["pooled"].clone()
+
+    b_all, pooled_all = run(X, sizes)
+    ns = b_all.n_sel.cpu()
+    assert int(ns.max()) <= j * (2 * C + 2) and int(ns.min()) >= j
+    # (1) one slide alone == the same slide inside the batch
+    _, p3 = run(bags[3].contiguous(), [sizes[3]])
+    assert torch.equal(p3[0], pooled_all[3])
+    # (2) permuting a slide's rows permutes selected_index, nothing else
+    perm = torch.randperm(sizes[3], device=dev)
+    bp, pp = run(bags[3][perm].contiguous(), [sizes[3]])
+    np.testing.assert_allclose(pp[0].cpu().numpy(), pooled_all[3].cpu().numpy(), atol=1e-6)
+    S = int(bp.n_sel[0])
+    o = b_all.row_off_host[3]
+    orig = set(b_all.sel_idx[o:o + int(ns[3])].cpu().tolist())
+    assert set(perm[bp.sel_idx[:S].long()].cpu().tolist()) == orig
+    # (3) evaluation over the 32 slides agrees with the oracle on the same bytes
+    cpu_bags = [b.cpu() for b in bags]
+    torch.manual_seed(0)
+    ref_model = O.Senet(512, 4)
+    ev_ref, ref_pooled = O.evaluation(ref_model, cpu_bags, labels, W, We, C, j, K, return_logits=True)
+    np.testing.assert_allclose(pooled_all.cpu().numpy(), ref_pooled.numpy(), atol=ATOL)
+    ev = M.evaluation(model, H.ListLoader(cpu_bags, labels), dev, args)
+    assert abs(ev["loss"] - ev_ref["loss"]) < ATOL and ev["acc"] == ev_ref["acc"] and abs(ev["auc"] - ev_ref["auc"]) < 2e-3
