@@ -7,6 +7,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch first, always: its wheel bundles the HIP runtime (SONAME libamdhip64.so.7).  Loaded
+# before libmoc_hip.so, the dynamic linker binds our NEEDED libamdhip64.so.7 to that same
+# copy, so our launches share torch's streams and allocations.  Loaded after, a second HIP
+# runtime would come up from /opt/rocm and find no usable device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmoc_hip.so")
 ABI_VERSION = 1
@@ -78,6 +84,7 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `make -C moc_amd/csrc` "
                 "(or __graft_entry__.build()).  moc_amd has no CPU fallback.")
         h = C.CDLL(LIB_PATH)
+        _assert_single_hip_runtime()
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
@@ -85,6 +92,16 @@ def lib():
             raise RuntimeError(f"libmoc_hip ABI {h.moc_version()} != binding {ABI_VERSION}; rebuild")
         _lib = h
     return _lib
+
+
+def _assert_single_hip_runtime():
+    try:
+        maps = open("/proc/self/maps").read()
+    except OSError:
+        return
+    copies = {line.split()[-1] for line in maps.splitlines() if "libamdhip64.so" in line}
+    if len(copies) > 1:
+        raise RuntimeError(f"two HIP runtimes in one process ({sorted(copies)}): import torch before moc_amd")
 
 
 def check(rc: int, what: str):

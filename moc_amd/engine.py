@@ -15,6 +15,10 @@ from ._lib import MocBatch, MocMeta, MocMetaWs, check, lib, ptr
 
 HIDDEN = 64
 
+# bench.py sets this to a list: every batched score-pass launch then appends
+# (start_event, stop_event, algorithmic_bytes) recorded on the launch stream.
+SCORE_EVENTS = None
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -91,8 +95,11 @@ class SlideBatch:
             self.x_off = torch.tensor([int(v) for v in x_starts], dtype=torch.int64).to(dev, non_blocking=True)
         T, n = self.total, self.n_slides
         self.mask = None
+        self.kept_rows_host = T          # rows the score pass has to read (algorithmic)
         if mask is not None:
             assert mask.numel() == T
+            if not mask.is_cuda:
+                self.kept_rows_host = int(mask.sum())
             self.mask = mask.to(torch.uint8).to(dev, non_blocking=True).contiguous()
         i32 = dict(dtype=torch.int32, device=dev)
         self.kept = torch.empty(T, **i32) if mask is not None else None
@@ -114,7 +121,18 @@ class SlideBatch:
     # ---- phase A ----
     def phase_a(self, bank: Bank):
         assert bank.D == self.D and bank.C == self.C and bank.Ce == self.Ce and bank.dtype == self.X.dtype
-        check(lib().moc_phase_a(C.byref(self.c), ptr(bank.image), _stream()), "moc_phase_a")
+        if SCORE_EVENTS is None:
+            check(lib().moc_phase_a(C.byref(self.c), ptr(bank.image), _stream()), "moc_phase_a")
+            return
+        # same four launches, with events around the score pass
+        check(lib().moc_mask_compact(C.byref(self.c), _stream()), "moc_mask_compact")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().moc_scores(C.byref(self.c), ptr(bank.image), _stream()), "moc_scores")
+        e1.record()
+        SCORE_EVENTS.append((e0, e1, self.kept_rows_host * self.D * self.X.element_size()))
+        self.select()
+        self.gather_candidates()
 
     def scores(self, bank: Bank):
         check(lib().moc_mask_compact(C.byref(self.c), _stream()), "moc_mask_compact")
