@@ -77,28 +77,77 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
     const unsigned char* xp = a.X + a.sel_row[base + s_c] * (int64_t)a.D * ESZ + (lane >> 4) * 16;
     const float* wp = a.W1 + (int64_t)(wave * 16 + (lane & 15)) * a.D;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    // K is walked in chunks of 128 elements: the chunk's x fragments and W1 fragments are all
+    // requested before the first MFMA of the chunk (sched_barrier keeps hipcc from re-serialising
+    // them), and the next chunk's loads are issued while this chunk's MFMAs run.
     if constexpr (BF16) {
         // 16 B of x = 8 bf16 = k offsets kk*32 + (lane>>4)*8 + j; W1 row read at the same k
-        for (int kk = 0; kk < a.D / 32; ++kk) {
-            const uint4 xv = *reinterpret_cast<const uint4*>(xp + kk * 64);
-            const float4 w0 = *reinterpret_cast<const float4*>(wp + kk * 32 + (lane >> 4) * 8);
-            const float4 w1 = *reinterpret_cast<const float4*>(wp + kk * 32 + (lane >> 4) * 8 + 4);
-            const uint32_t xs[4] = {xv.x, xv.y, xv.z, xv.w};
-            const float ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        constexpr int G = 4;                       // k-steps of 32 per chunk
+        const int nchunk = a.D / (32 * G);
+        uint4 xa[G], xb[G];
+        float4 wa[2 * G], wb[2 * G];
+        auto ld = [&](uint4 (&xv)[G], float4 (&wv)[2 * G], int ch) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xs[j] << 16), ws[2 * j], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xs[j] & 0xFFFF0000u), ws[2 * j + 1], acc, 0, 0, 0);
+            for (int q = 0; q < G; ++q) {
+                const int kk = ch * G + q;
+                xv[q] = *reinterpret_cast<const uint4*>(xp + kk * 64);
+                wv[2 * q] = *reinterpret_cast<const float4*>(wp + kk * 32 + (lane >> 4) * 8);
+                wv[2 * q + 1] = *reinterpret_cast<const float4*>(wp + kk * 32 + (lane >> 4) * 8 + 4);
             }
+        };
+        auto mm = [&](const uint4 (&xv)[G], const float4 (&wv)[2 * G]) {
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                const uint32_t xs[4] = {xv[q].x, xv[q].y, xv[q].z, xv[q].w};
+                const float ws[8] = {wv[2 * q].x, wv[2 * q].y, wv[2 * q].z, wv[2 * q].w,
+                                     wv[2 * q + 1].x, wv[2 * q + 1].y, wv[2 * q + 1].z, wv[2 * q + 1].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xs[j] << 16), ws[2 * j], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xs[j] & 0xFFFF0000u), ws[2 * j + 1], acc, 0, 0, 0);
+                }
+            }
+        };
+        ld(xa, wa, 0);
+        for (int ch = 0; ch < nchunk; ch += 2) {
+            if (ch + 1 < nchunk) ld(xb, wb, ch + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(xa, wa);
+            if (ch + 1 >= nchunk) break;
+            if (ch + 2 < nchunk) ld(xa, wa, ch + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(xb, wb);
         }
     } else {
-        for (int kq = 0; kq < a.D / 16; ++kq) {
-            const float4 xv = *reinterpret_cast<const float4*>(xp + kq * 64);
-            const float4 wv = *reinterpret_cast<const float4*>(wp + kq * 16 + (lane >> 4) * 4);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, wv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.y, wv.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.z, wv.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.w, wv.w, acc, 0, 0, 0);
+        constexpr int G = 8;                       // k-steps of 16 per chunk
+        const int nchunk = a.D / (16 * G);
+        float4 xa[G], xb[G], wa[G], wb[G];
+        auto ld = [&](float4 (&xv)[G], float4 (&wv)[G], int ch) {
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                const int kq = ch * G + q;
+                xv[q] = *reinterpret_cast<const float4*>(xp + kq * 64);
+                wv[q] = *reinterpret_cast<const float4*>(wp + kq * 16 + (lane >> 4) * 4);
+            }
+        };
+        auto mm = [&](const float4 (&xv)[G], const float4 (&wv)[G]) {
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[q].x, wv[q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[q].y, wv[q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[q].z, wv[q].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[q].w, wv[q].w, acc, 0, 0, 0);
+            }
+        };
+        ld(xa, wa, 0);
+        for (int ch = 0; ch < nchunk; ch += 2) {
+            if (ch + 1 < nchunk) ld(xb, wb, ch + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(xa, wa);
+            if (ch + 1 >= nchunk) break;
+            if (ch + 2 < nchunk) ld(xa, wa, ch + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(xb, wb);
         }
     }
     {   // acc[i] = pre-activation of row (lane>>4)*4+i, hidden unit wave*16 + (lane&15)
@@ -164,6 +213,7 @@ struct FinishArgs {
     const int32_t* n_sel;
     const float* cand;
     const float *H1, *gates, *pooled;
+    const float* mixed_in;          // fused kernel: [C, stride] mixed scores
     const int32_t *topk_idx, *topk_cnt;
     const int64_t* labels;
     float* loss;
@@ -259,6 +309,224 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------ fused pooling + loss (+ step)
+// top-K mean for every class, cross entropy, argmax and (train) the pair gradients with the
+// Adam step of b1/W2/b2 in ONE workgroup of 16 waves -- for K <= 16, C <= 16, S <= 4096.
+//
+// top-K without K block-wide reductions: element i lives on wave i%16.  The K-th largest of
+// the 16 per-wave maxima is a lower bound T0 of the K-th largest element (K waves hold an
+// element >= T0), so only elements >= T0 can be in the top-K: a few dozen out of thousands.
+// They go to a short LDS list per class, and one wave per class extracts them in value order
+// (K wave-wide max reductions over the short list, DPP row operations, no LDS round trips).
+constexpr int PS_VPT = 4;       // values per thread per class  (S <= 4096)
+constexpr int PS_CAP = 512;     // candidate list entries per class
+
+// inclusive max-scan by DPP row shifts, then the wave total from lane 63 (gfx9 DPP controls:
+// row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#define MOC_DPP_STEP(ctrl, rmask)                                                                  \
+    {                                                                                              \
+        const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, ctrl, rmask, 0xf, false); \
+        const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, ctrl, rmask, 0xf, false); \
+        const bool gt = ohi > hi || (ohi == hi && olo > lo);                                       \
+        lo = gt ? olo : lo;                                                                        \
+        hi = gt ? ohi : hi;                                                                        \
+    }
+    MOC_DPP_STEP(0x111, 0xf) MOC_DPP_STEP(0x112, 0xf) MOC_DPP_STEP(0x114, 0xf) MOC_DPP_STEP(0x118, 0xf)
+    MOC_DPP_STEP(0x142, 0xa) MOC_DPP_STEP(0x143, 0xc)
+#undef MOC_DPP_STEP
+    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ float key_to_float(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+// element e of thread (wave, lane): position i = (q*64 + lane)*16 + wave
+__device__ __forceinline__ unsigned long long ps_key(const float* col, int i, int S) {
+    return i < S ? ((unsigned long long)moc_key_desc(col[i]) << 32) | (unsigned)(~(unsigned)i) : 0ull;
+}
+
+// grid (n): one workgroup (1024 threads) per slide
+__global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* pooled_out, int32_t* topk_idx_out,
+                                                         int32_t* topk_cnt_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = a.slide0 + blockIdx.x, C = a.C, K = a.K;
+    const int64_t base = a.row_off[b];
+    const int S = a.n_sel[b];
+    const int k = K < S ? K : S;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // LDS carve (all dynamic)
+    unsigned long long* list = reinterpret_cast<unsigned long long*>(smem);          // [C][PS_CAP]
+    unsigned long long* wmax = list + (size_t)C * PS_CAP;                           // [C][16]
+    float* pooled_s = reinterpret_cast<float*>(wmax + (size_t)C * 16);               // [C]
+    float* dpool = pooled_s + C;                                                     // [C]
+    int* ncand = reinterpret_cast<int*>(dpool + C);                                  // [C]
+    int* topk_s = ncand + C;                                                         // [C][K]
+    float* dz = reinterpret_cast<float*>(topk_s + C * K);                            // [P][4]   (train)
+    int* prow = reinterpret_cast<int*>(dz + (size_t)C * K * 4);                      // [P]
+    float* H1s = reinterpret_cast<float*>(prow + C * K);                             // [P][H]
+    float* dhs = H1s + (size_t)C * K * H;                                            // [P][H]
+    float* W2s = dhs + (size_t)C * K * H;                                            // [4][H]
+
+    if (threadIdx.x < C) ncand[threadIdx.x] = 0;
+    if (k > 0) {
+        // ---- per-wave maxima
+        for (int c = 0; c < C; ++c) {
+            const float* col = a.mixed_in + (int64_t)c * a.stride + base;
+            unsigned long long m = 0;
+#pragma unroll
+            for (int q = 0; q < PS_VPT; ++q) {
+                const unsigned long long v = ps_key(col, (q * 64 + lane) * 16 + wave, S);
+                m = v > m ? v : m;
+            }
+            m = wave_max_u64(m);
+            if (lane == 0) wmax[c * 16 + wave] = m;
+        }
+    }
+    __syncthreads();
+    if (k > 0) {
+        // ---- threshold + candidates
+        for (int c = 0; c < C; ++c) {
+            const unsigned long long mine = wmax[c * 16 + (lane & 15)];
+            int rank = 0;
+#pragma unroll
+            for (int l = 0; l < 16; ++l) rank += wmax[c * 16 + l] > mine ? 1 : 0;
+            // K-th largest wave maximum (keys are unique; zero = empty wave)
+            const unsigned long long hit = __ballot(lane < 16 && rank == k - 1 && mine != 0ull);
+            unsigned long long T0 = 0ull;
+            if (hit != 0ull && k <= 16) {
+                const int src = __ffsll((long long)hit) - 1;
+                const unsigned lo = (unsigned)__shfl((int)(unsigned)mine, src, 64);
+                const unsigned hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), src, 64);
+                T0 = ((unsigned long long)hi << 32) | lo;
+            }
+            const float* col = a.mixed_in + (int64_t)c * a.stride + base;
+#pragma unroll
+            for (int q = 0; q < PS_VPT; ++q) {
+                const unsigned long long v = ps_key(col, (q * 64 + lane) * 16 + wave, S);
+                if (v != 0ull && v >= T0) {
+                    const int pos = atomicAdd(&ncand[c], 1);
+                    if (pos < PS_CAP) list[(size_t)c * PS_CAP + pos] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- extraction: wave w takes classes w, w+16, ...
+    for (int c = wave; c < C; c += 16) {
+        float sum = 0.f;
+        if (k > 0) {
+            const int n = ncand[c];
+            const bool overflow = n > PS_CAP;        // pathological ties: rank straight from global
+            const float* col = a.mixed_in + (int64_t)c * a.stride + base;
+            unsigned long long prev = ~0ull;
+            for (int r = 0; r < k; ++r) {
+                unsigned long long best = 0ull;
+                if (!overflow) {
+                    for (int i = lane; i < n; i += 64) {
+                        const unsigned long long v = list[(size_t)c * PS_CAP + i];
+                        if (v < prev && v > best) best = v;
+                    }
+                } else {
+                    for (int i = lane; i < S; i += 64) {
+                        const unsigned long long v = ps_key(col, i, S);
+                        if (v < prev && v > best) best = v;
+                    }
+                }
+                best = wave_max_u64(best);
+                prev = best;
+                sum += key_to_float((unsigned)(best >> 32));           // value order: largest first
+                if (lane == 0) topk_s[c * K + r] = (int)(~(unsigned)best);
+            }
+        }
+        if (lane == 0) {
+            const float pv = k > 0 ? sum / (float)k : __uint_as_float(0x7FC00000u);   // empty mean = NaN
+            pooled_s[c] = pv;
+            pooled_out[(int64_t)b * C + c] = pv;
+            if (topk_cnt_out) topk_cnt_out[(int64_t)b * C + c] = k;
+        }
+        if (topk_idx_out)
+            for (int r = lane; r < K; r += 64)
+                topk_idx_out[((int64_t)b * C + c) * K + r] = r < k ? topk_s[c * K + r] : -1;
+    }
+    __syncthreads();
+    // ---- cross entropy, argmax
+    const int y = (int)a.labels[b];
+    if (threadIdx.x == 0) {
+        float mx = -INFINITY;
+        int arg = 0;
+        for (int c = 0; c < C; ++c) if (pooled_s[c] > mx) { mx = pooled_s[c]; arg = c; }
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(pooled_s[c] - mx);
+        const float lse = mx + logf(se);
+        a.loss[b] = lse - pooled_s[y];
+        a.pred[b] = arg;
+        if (a.train) for (int c = 0; c < C; ++c) dpool[c] = expf(pooled_s[c] - lse) - (c == y ? 1.f : 0.f);
+    }
+    if (!a.train) return;
+    for (int e = threadIdx.x; e < 4 * H; e += 1024) W2s[e] = a.W2[e];
+    __syncthreads();
+    // ---- pairs p = (class c, r-th pooled row): dz, gathered H1 rows
+    const int P = C * k;
+    for (int p = threadIdx.x; p < P; p += 1024) {
+        const int c = p / k, r = p - c * k;
+        const int sidx = topk_s[c * K + r];
+        prow[p] = sidx;
+        const float g = dpool[c] / (float)k;
+        const float* cd = a.cand + base + sidx;
+        const float sc[4] = {cd[(int64_t)c * a.stride], cd[(int64_t)(C + c) * a.stride],
+                             cd[(int64_t)(2 * C) * a.stride], cd[(int64_t)(2 * C + 1) * a.stride]};
+        const float4 lam4 = *reinterpret_cast<const float4*>(a.gates + (base + sidx) * 4);
+        const float lam[4] = {lam4.x, lam4.y, lam4.z, lam4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dlam = (a.use_bits >> i & 1u) ? g * sc[i] : 0.f;
+            dz[p * 4 + i] = dlam * lam[i] * (1.f - lam[i]);
+        }
+        a.pair_row[p] = a.sel_row[base + sidx];
+    }
+    if (threadIdx.x == 0) *a.n_pair = P;
+    __syncthreads();
+    for (int e = threadIdx.x; e < P * H; e += 1024) H1s[e] = a.H1[(base + prow[e >> 6]) * H + (e & 63)];
+    __syncthreads();
+    // dh[p][h] = (sum_i dz[p][i] * W2[i][h]) * [H1 > 0]
+    for (int e = threadIdx.x; e < P * H; e += 1024) {
+        const int p = e >> 6, h = e & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v = fmaf(dz[p * 4 + i], W2s[i * H + h], v);
+        v = H1s[e] > 0.f ? v : 0.f;
+        dhs[e] = v;
+        a.pair_dh[e] = v;
+    }
+    __syncthreads();
+    const float gs = a.adam.grad_scale;
+    if (threadIdx.x < 4 * H) {          // W2 [4][H]
+        const int i = threadIdx.x >> 6, h = threadIdx.x & 63;
+        float g = 0.f;
+        for (int p = 0; p < P; ++p) g = fmaf(dz[p * 4 + i], H1s[p * H + h], g);
+        if (a.apply_adam) adam_update(a.W2[threadIdx.x], a.m_W2[threadIdx.x], a.v_W2[threadIdx.x], g * gs, a.adam);
+        else a.g_W2[threadIdx.x] = g;
+    } else if (threadIdx.x < 4 * H + 4) {
+        const int i = threadIdx.x - 4 * H;
+        float g = 0.f;
+        for (int p = 0; p < P; ++p) g += dz[p * 4 + i];
+        if (a.apply_adam) adam_update(a.b2[i], a.m_b2[i], a.v_b2[i], g * gs, a.adam);
+        else a.g_b2[i] = g;
+    } else if (threadIdx.x >= 320 && threadIdx.x < 320 + H) {
+        const int h = threadIdx.x - 320;
+        float g = 0.f;
+        for (int p = 0; p < P; ++p) g += dhs[p * H + h];
+        if (a.apply_adam) adam_update(a.b1[h], a.m_b1[h], a.v_b1[h], g * gs, a.adam);
+        else a.g_b1[h] = g;
+    }
+}
+
 // ------------------------------------------------------------------ W1 gradient (+ Adam)
 struct W1Args {
     const unsigned char* X;
@@ -270,22 +538,41 @@ struct W1Args {
     AdamCoef adam;
 };
 
-// grid (H*D/256): thread -> element (h, d); dW1[h][d] = sum_p dh[p][h] * x_p[d]
+// dW1[h][d] = sum_p dh[p][h] * x_p[d] over the <= K*C gradient pairs, then Adam in place.
+// grid (D/256, H/8): a workgroup owns 256 columns d and 8 hidden units; the pairs' row segments
+// (P x 256 elements) and dh columns are staged in LDS with every load issued at once -- one
+// memory round trip instead of P dependent ones.
+constexpr int W1_MAXP = 64;
 template <bool BF16>
 __global__ __launch_bounds__(256) void w1_update_kernel(W1Args a) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    const int h = e / a.D, d = e - h * a.D;
+    __shared__ float xs[W1_MAXP][256];
+    __shared__ float dh_s[W1_MAXP][8];
+    const int d = blockIdx.x * 256 + threadIdx.x, h0 = blockIdx.y * 8;
     const int P = *a.n_pair;
-    float g = 0.f;
-    for (int p = 0; p < P; ++p) {
-        const int64_t row = a.pair_row[p];
-        float xv;
-        if constexpr (BF16) xv = moc_bf16_to_f32(reinterpret_cast<const uint16_t*>(a.X)[row * a.D + d]);
-        else xv = reinterpret_cast<const float*>(a.X)[row * a.D + d];
-        g = fmaf(a.pair_dh[p * H + h], xv, g);
+    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p0 = 0; p0 < P; p0 += W1_MAXP) {
+        const int np = P - p0 < W1_MAXP ? P - p0 : W1_MAXP;
+        if (p0 > 0) __syncthreads();
+#pragma unroll 8
+        for (int p = 0; p < np; ++p) {
+            const int64_t row = a.pair_row[p0 + p];
+            if constexpr (BF16) xs[p][threadIdx.x] = moc_bf16_to_f32(reinterpret_cast<const uint16_t*>(a.X)[row * a.D + d]);
+            else xs[p][threadIdx.x] = reinterpret_cast<const float*>(a.X)[row * a.D + d];
+        }
+        for (int e = threadIdx.x; e < np * 8; e += 256) dh_s[e >> 3][e & 7] = a.pair_dh[(p0 + (e >> 3)) * H + h0 + (e & 7)];
+        __syncthreads();
+        for (int p = 0; p < np; ++p) {
+            const float xv = xs[p][threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = fmaf(dh_s[p][j], xv, g[j]);
+        }
     }
-    if (a.apply_adam) adam_update(a.W1[e], a.m_W1[e], a.v_W1[e], g * a.adam.grad_scale, a.adam);
-    else a.g_W1[e] = g;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int e = (h0 + j) * a.D + d;
+        if (a.apply_adam) adam_update(a.W1[e], a.m_W1[e], a.v_W1[e], g[j] * a.adam.grad_scale, a.adam);
+        else a.g_W1[e] = g[j];
+    }
 }
 
 // gradients already in g_* (e.g. after an all-reduce): plain Adam over all four tensors
@@ -378,12 +665,46 @@ int launch_finish(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t
     return MOC_OK;
 }
 
+bool fused_ok(const moc_batch_t* B, int train) {
+    return B->topk <= 16 && B->C <= 16 && s_bound(B) <= 64 * 16 * PS_VPT && (!train || B->C * B->topk <= 64);
+}
+
+// pooling + loss (+ pair gradients and the small-parameter step) for slides [slide0, slide0+n)
+int launch_pool_finish(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels,
+                       int slide0, int n, int train, int apply_adam, uint32_t use_bits, const AdamCoef& k,
+                       hipStream_t s) {
+    if (!fused_ok(B, train)) {
+        if (int rc = launch_pool(B, ws, slide0, n, s)) return rc;
+        return launch_finish(B, M, ws, labels, slide0, n, train, apply_adam, use_bits, k, s);
+    }
+    FinishArgs a = {};
+    a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel; a.cand = B->cand;
+    a.H1 = ws->H1; a.gates = ws->gates; a.pooled = ws->pooled; a.mixed_in = ws->mixed;
+    a.labels = labels; a.loss = ws->loss; a.pred = ws->pred;
+    a.W2 = M->W2; a.b2 = M->b2; a.b1 = M->b1;
+    a.m_W2 = M->m_W2; a.m_b2 = M->m_b2; a.m_b1 = M->m_b1; a.v_W2 = M->v_W2; a.v_b2 = M->v_b2; a.v_b1 = M->v_b1;
+    a.g_W2 = M->g_W2; a.g_b2 = M->g_b2; a.g_b1 = M->g_b1;
+    a.pair_dh = ws->pair_dh; a.pair_row = ws->pair_row; a.n_pair = ws->n_pair;
+    a.stride = B->total_rows; a.C = B->C; a.K = B->topk; a.slide0 = slide0; a.train = train;
+    a.apply_adam = apply_adam; a.use_bits = use_bits; a.adam = k;
+    const size_t C = B->C, K = B->topk, PK = train ? C * K : 0;
+    const size_t smem = C * PS_CAP * 8 + C * 16 * 8 + C * 4 * 3 + C * K * 4 + PK * (4 * 4 + 4 + 2 * H * 4) + 4 * H * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)pool_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    pool_step_kernel<<<n, 1024, smem, s>>>(a, ws->pooled, ws->topk_idx, ws->topk_cnt);
+    MOC_CHECK_LAUNCH("moc_pool_step");
+    return MOC_OK;
+}
+
 int launch_w1(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, int apply_adam,
               const AdamCoef& k, hipStream_t s) {
     W1Args a;
     a.X = (const unsigned char*)B->X; a.pair_dh = ws->pair_dh; a.pair_row = ws->pair_row; a.n_pair = ws->n_pair;
     a.W1 = M->W1; a.m_W1 = M->m_W1; a.v_W1 = M->v_W1; a.g_W1 = M->g_W1; a.D = B->D; a.apply_adam = apply_adam; a.adam = k;
-    const int grid = H * B->D / 256;
+    const dim3 grid(B->D / 256, H / 8);
     if (B->dtype == MOC_BF16) w1_update_kernel<true><<<grid, 256, 0, s>>>(a);
     else w1_update_kernel<false><<<grid, 256, 0, s>>>(a);
     MOC_CHECK_LAUNCH("moc_w1_update");
@@ -421,10 +742,9 @@ extern "C" int moc_pool_loss(const moc_batch_t* B, const moc_meta_ws_t* ws, cons
     MOC_REQUIRE(slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_pool_loss: bad slide range");
     MOC_REQUIRE(B->C <= 256, "moc_pool_loss: C > 256");
     hipStream_t s = (hipStream_t)stream;
-    if (int rc = launch_pool(B, ws, slide0, n, s)) return rc;
     moc_meta_t none = {};
     AdamCoef k = {};
-    return launch_finish(B, &none, ws, labels, slide0, n, 0, 0, 0, k, s);
+    return launch_pool_finish(B, &none, ws, labels, slide0, n, 0, 0, 0, k, s);
 }
 
 extern "C" int moc_ce_loss(const float* pooled, const int64_t* labels, int n, int C, float* loss, int32_t* pred,
@@ -473,8 +793,7 @@ extern "C" int moc_train_steps(const moc_batch_t* B, const moc_meta_t* M, const 
         const int b = slide0 + t;
         const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f);
         if (int rc = launch_forward(B, M, ws, b, 1, use_bits, s)) return rc;
-        if (int rc = launch_pool(B, ws, b, 1, s)) return rc;
-        if (int rc = launch_finish(B, M, ws, labels, b, 1, 1, 1, use_bits, k, s)) return rc;
+        if (int rc = launch_pool_finish(B, M, ws, labels, b, 1, 1, 1, use_bits, k, s)) return rc;
         if (int rc = launch_w1(B, M, ws, 1, k, s)) return rc;
     }
     return MOC_OK;

@@ -210,6 +210,142 @@ __global__ __launch_bounds__(256) void scores_kernel(ScoresArgs a) {
     }
 }
 
+// ---- streaming form for Ct <= 16 (one n-tile): persistent workgroups ---------------
+// The generic kernel above leaves the load schedule to the compiler, which keeps two
+// 1-KiB loads in flight per wave (24 KB per CU: ~3 TB/s).  Here every wave walks a flat
+// list of 16-row tiles (all slides of the batch), the bank image is staged once per
+// workgroup, and the A fragments are double buffered by hand: all NF loads of the NEXT
+// unit are issued before the MFMAs of the current one, so each wave keeps >= NF KiB in
+// flight.  A unit = NF*64 bytes of each of the tile's 16 rows (NF = 16: 1 KiB).
+template <int NF, bool BF16>
+__global__ __launch_bounds__(256, 2) void scores_stream_kernel(ScoresArgs a, int n_slides) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ESZ = BF16 ? 2 : 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row_bytes = (int64_t)a.D * ESZ;
+    const int U = (int)(row_bytes / (NF * 64));                  // units per tile
+    const int img_bytes = BF16 ? (a.D / 32) * 3 * 1024 : (a.D / 16) * 1024;
+    constexpr int LDT = 17;
+    uint4* lds_b = reinterpret_cast<uint4*>(smem);
+    float* tile = reinterpret_cast<float*>(smem + img_bytes) + wave * 16 * LDT;
+    // [n_slides] first slot, [n_slides] first X row, [n_slides + 1] tile prefix, [n_slides] kept rows
+    int64_t* s_base = reinterpret_cast<int64_t*>(smem + img_bytes + 4 * 16 * LDT * sizeof(float));
+    int64_t* s_xbase = s_base + n_slides;
+    int* prefix = reinterpret_cast<int*>(s_xbase + n_slides);
+    int* s_nk = prefix + n_slides + 1;
+
+    {   // bank image -> LDS, four 16-B loads in flight per thread
+        const uint4* src = reinterpret_cast<const uint4*>(a.bank);
+        const int nvec = img_bytes / 16;
+        int i = threadIdx.x;
+        for (; i + 3 * 256 < nvec; i += 4 * 256) {
+            const uint4 t0 = src[i], t1 = src[i + 256], t2 = src[i + 512], t3 = src[i + 768];
+            lds_b[i] = t0; lds_b[i + 256] = t1; lds_b[i + 512] = t2; lds_b[i + 768] = t3;
+        }
+        for (; i < nvec; i += 256) lds_b[i] = src[i];
+    }
+    // per-slide metadata in LDS so that locating a tile costs no dependent global loads
+    for (int b = threadIdx.x; b < n_slides; b += 256) {
+        const int64_t base = a.row_off[b];
+        s_base[b] = base;
+        s_xbase[b] = a.x_off ? a.x_off[b] : base;
+        s_nk[b] = a.kept ? a.n_kept[b] : (int)(a.row_off[b + 1] - base);
+    }
+    __syncthreads();
+    if (wave == 0) {   // prefix[b] = tiles of slides < b
+        int carry = 0;
+        for (int c0 = 0; c0 < n_slides; c0 += 64) {
+            const int b = c0 + lane;
+            int v = 0;
+            if (b < n_slides) v = (s_nk[b] + 15) >> 4;
+            int inc = v;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += o;
+            }
+            if (b < n_slides) prefix[b + 1] = carry + inc;
+            carry += __shfl(inc, 63, 64);
+        }
+        if (lane == 0) prefix[0] = 0;
+    }
+    __syncthreads();
+    const int total = prefix[n_slides];
+    const int stride = gridDim.x * 4;
+
+    struct Unit { const unsigned char* p; int64_t base; int row0, nk, kk0; bool last; };
+    auto locate = [&](int g, int ch, Unit& u) {
+        int lo = 0, hi = n_slides;                 // prefix[lo] <= g < prefix[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= g) lo = mid; else hi = mid; }
+        const int b = lo;
+        u.base = s_base[b];
+        const int64_t xbase = s_xbase[b];
+        u.nk = s_nk[b];
+        u.row0 = (g - prefix[b]) * 16;
+        const int slot = u.row0 + (lane & 15);
+        const int slot_c = slot < u.nk ? slot : u.nk - 1;          // clamp: loads stay in bounds
+        const int r = a.kept ? a.kept[u.base + slot_c] : slot_c;
+        u.p = a.X + (xbase + r) * row_bytes + (lane >> 4) * 16 + (int64_t)ch * NF * 64;
+        u.kk0 = ch * NF;
+        u.last = ch == U - 1;
+    };
+    auto load = [&](uint4 (&buf)[NF], const Unit& u) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) buf[f] = *reinterpret_cast<const uint4*>(u.p + f * 64);
+    };
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const uint4 (&buf)[NF], const Unit& u) {
+        if constexpr (BF16) {
+            const uint4* bp = lds_b + u.kk0 * 3 * 64 + lane;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const bf16x8_t A = __builtin_bit_cast(bf16x8_t, buf[f]);
+#pragma unroll
+                for (int term = 0; term < 3; ++term) {
+                    const bf16x8_t Bv = __builtin_bit_cast(bf16x8_t, bp[(f * 3 + term) * 64]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bv, acc, 0, 0, 0);
+                }
+            }
+        } else {
+            const uint4* bp = lds_b + u.kk0 * 64 + lane;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const uint4 bv = bp[f * 64];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f].x), __uint_as_float(bv.x), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f].y), __uint_as_float(bv.y), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f].z), __uint_as_float(bv.z), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f].w), __uint_as_float(bv.w), acc, 0, 0, 0);
+            }
+        }
+        if (u.last) {
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tile[((lane >> 4) * 4 + i) * LDT + (lane & 15)] = acc[i];
+            wave_lds_sync();
+            if (lane < 16) row_epilogue(a, tile + lane * LDT, LDT, u.base, u.row0 + lane, u.row0 + lane < u.nk);
+            acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // flattened (tile, unit) walk, two register buffers
+    int g = blockIdx.x * 4 + wave, ch = 0;
+    auto advance = [&]() { if (++ch == U) { ch = 0; g += stride; } };
+    uint4 bufA[NF], bufB[NF];
+    Unit uA, uB;
+    if (g < total) { locate(g, ch, uA); load(bufA, uA); }
+    while (g < total) {
+        advance();
+        const bool moreB = g < total;
+        if (moreB) { locate(g, ch, uB); load(bufB, uB); }
+        __builtin_amdgcn_sched_barrier(0);
+        compute(bufA, uA);
+        if (!moreB) break;
+        advance();
+        const bool moreA = g < total;
+        if (moreA) { locate(g, ch, uA); load(bufA, uA); }
+        __builtin_amdgcn_sched_barrier(0);
+        compute(bufB, uB);
+    }
+}
+
 // Row statistics from a given logits matrix [N, Ct] (row-major): same columns as the score
 // pass writes.  One thread per row; used by the helpers that take logits, not bags.
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* logits, int64_t N, int Ct, int C,
@@ -303,15 +439,42 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
     a.sel_flag = B->sel_flag;
     a.stride = B->total_rows;
     a.D = B->D; a.C = B->C; a.Ce = B->Ce; a.NT = bank_nt(B->Ce);
-    // rows per workgroup: 256 when the launch is big enough to fill the chip, else 64
-    const int64_t tiles64 = (int64_t)moc_cdiv(B->max_rows, 64) * B->n_slides;
-    a.tpw = (a.NT == 1 && tiles64 >= 4096) ? 4 : 1;
     const bool bf = B->dtype == MOC_BF16;
     const size_t img = bf ? (size_t)(B->D / 32) * 3 * 1024 : (size_t)(B->D / 16) * 1024;
+    hipStream_t s = (hipStream_t)stream;
+    if (a.NT == 1) {
+        // streaming form: persistent workgroups over the flat tile list
+        a.tpw = 0;
+        const size_t smem = img + 4 * 16 * 17 * sizeof(float) + (size_t)B->n_slides * 24 + 16;
+        MOC_REQUIRE(smem <= 160 * 1024, "moc_scores: D=%d / n_slides=%d need %zu B of LDS (> 160 KiB)", B->D, B->n_slides, smem);
+        int64_t tiles = 0;   // upper bound from the host-known sizes
+        tiles = (B->total_rows + 15) / 16 + B->n_slides;
+        int wgs = (int)((tiles + 3) / 4);
+        const int resident = 256 * (smem <= 80 * 1024 ? 2 : 1);
+        if (wgs > resident) wgs = resident;
+        const int row_b = B->D * moc_elem_size(B->dtype);
+#define MOC_LAUNCH_STREAM(NF, BF)                                                                       \
+        do {                                                                                            \
+            static bool attr_set = false;                                                               \
+            if (!attr_set) {                                                                            \
+                (void)hipFuncSetAttribute((const void*)scores_stream_kernel<NF, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                attr_set = true;                                                                        \
+            }                                                                                           \
+            scores_stream_kernel<NF, BF><<<wgs, 256, smem, s>>>(a, B->n_slides);                        \
+        } while (0)
+        if (row_b % 1024 == 0) {
+            if (bf) MOC_LAUNCH_STREAM(16, true); else MOC_LAUNCH_STREAM(16, false);
+        } else {
+            if (bf) MOC_LAUNCH_STREAM(8, true); else MOC_LAUNCH_STREAM(8, false);
+        }
+#undef MOC_LAUNCH_STREAM
+        MOC_CHECK_LAUNCH("moc_scores(stream)");
+        return MOC_OK;
+    }
+    a.tpw = 1;
     const size_t smem = img + (size_t)4 * 16 * (a.NT * 16 + 1) * sizeof(float);
     MOC_REQUIRE(smem <= 160 * 1024, "moc_scores: D=%d needs %zu B of LDS (> 160 KiB)", B->D, smem);
     dim3 grid(moc_cdiv(B->max_rows, 64 * a.tpw), B->n_slides), block(256);
-    hipStream_t s = (hipStream_t)stream;
 #define MOC_LAUNCH_SCORES(CH, BF)                                                                       \
     do {                                                                                                \
         static bool attr_set = false;                                                                   \

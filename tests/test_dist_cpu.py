@@ -1,0 +1,148 @@
+"""world_size-2 gloo tests of the multi-GPU host logic (moc_amd/dist.py): slide
+sharding, the single flat-buffer meta-gradient all-reduce, and the ragged gather
+used by sharded evaluation.  Gradients here come from the oracle (CPU) -- the
+collective plumbing is what is under test; the kernels have their own GPU tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from moc_amd import dist as mdist
+from moc_amd import synth
+from oracle import moc_oracle as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(fn, world, *args):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q, args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        r, val = q.get(timeout=180)
+        out[r] = val
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, v in out.items():
+        if isinstance(v, str) and v.startswith("ERR"):
+            raise AssertionError(f"rank {r}: {v}")
+    return out
+
+
+def _entry(fn, rank, world, port, q, args):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        q.put((rank, fn(rank, world, *args)))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "ERR " + traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ pure functions
+def test_shard_indices_partition_and_balance():
+    sizes = [15000, 2000, 60000, 9000, 9000, 31000, 4000, 12000, 800]
+    for world in (1, 2, 3, 8):
+        parts = [mdist.shard_indices(len(sizes), r, world, sizes) for r in range(world)]
+        assert sorted(i for p in parts for i in p) == list(range(len(sizes)))
+        loads = [sum(sizes[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(sizes)          # greedy longest-first bound
+        rr = [mdist.shard_indices(10, r, world) for r in range(world)]
+        assert sorted(i for p in rr for i in p) == list(range(10))
+
+
+def test_flat_grads_views_alias_one_buffer():
+    params = [torch.zeros(64, 512), torch.zeros(64), torch.zeros(4, 64), torch.zeros(4)]
+    fg = mdist.FlatGrads(params, "cpu")
+    assert fg.flat.numel() == 33092
+    fg.views[2].fill_(3.0)
+    assert float(fg.flat[64 * 512 + 64]) == 3.0 and float(fg.flat.sum()) == 3.0 * 256
+    assert mdist.allreduce_mean_(fg.flat) == 1.0             # no process group: identity, scale 1
+
+
+def test_unshard_restores_item_order():
+    lists = [[0, 3, 4], [1, 2]]
+    rows = torch.tensor([[0.], [3.], [4.], [1.], [2.]])
+    assert mdist.unshard(rows, lists, 5).flatten().tolist() == [0., 1., 2., 3., 4.]
+
+
+# ------------------------------------------------------------------ world_size 2
+def _dp_step_worker(rank, world, seed):
+    """Each rank differentiates ITS slide; after the fused all-reduce every rank holds the mean
+    gradient and takes the same Adam step == one process doing a batch of `world` slides."""
+    C, j, K = 2, 100, 10
+    W, We = synth.make_bank(seed, 512, C)
+    bags, labels = synth.make_slide_set(seed + 1, [700, 900], 512, We, C)
+    masks = []
+    torch.manual_seed(seed)
+    for b in bags:
+        masks.append(O.draw_mask(b.size(0)))
+    torch.manual_seed(seed + 7)
+    model = O.Senet(512, 4)
+    opt = O.make_optimizer(model)
+    params = list(model.parameters())
+    fg = mdist.FlatGrads(params, "cpu")
+
+    def grad_of(m, i):
+        sr = O.slide_process(bags[i], W, We, C, j, mask=masks[i])
+        pooled = O.pool_top(O.mix_train(m(sr["selected_feat"]), sr), [K])[1][K]
+        loss = torch.nn.functional.cross_entropy(pooled, torch.tensor([labels[i]]))
+        return torch.autograd.grad(loss, list(m.parameters()))
+
+    for v, g in zip(fg.views, grad_of(model, rank)):
+        v.copy_(g)
+    scale = mdist.allreduce_mean_(fg.flat)
+    assert scale == 1.0 / world
+    for p, v in zip(params, fg.views):
+        p.grad = v * scale
+    opt.step()
+    got = torch.cat([p.detach().reshape(-1) for p in params])
+    # single-process reference: mean of the two slides' gradients, same Adam
+    torch.manual_seed(seed + 7)
+    ref = O.Senet(512, 4)
+    ropt = O.make_optimizer(ref)
+    g0, g1 = grad_of(ref, 0), grad_of(ref, 1)
+    for p, a, b in zip(ref.parameters(), g0, g1):
+        p.grad = (a + b) / 2
+    ropt.step()
+    exp = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+    return float((got - exp).abs().max()), got.numpy()
+
+
+def test_dp_meta_gradient_allreduce_world2():
+    out = _run(_dp_step_worker, 2, 321)
+    assert out[0][0] < 1e-6 and out[1][0] < 1e-6
+    assert np.array_equal(out[0][1], out[1][1]), "ranks diverged after the all-reduced step"
+
+
+def _gather_worker(rank, world):
+    n_items, C = 7, 3
+    sizes = [5000, 100, 3000, 2500, 2500, 400, 9000]
+    lists = [mdist.shard_indices(n_items, r, world, sizes) for r in range(world)]
+    mine = lists[rank]
+    local = torch.tensor([[10.0 * i + c for c in range(C)] + [float(i)] for i in mine])     # [n_local, C+1]
+    allv = mdist.unshard(mdist.gather_rows(local, [len(l) for l in lists]), lists, n_items)
+    return allv.numpy()
+
+
+def test_sharded_eval_gather_world2():
+    out = _run(_gather_worker, 2)
+    exp = np.array([[10.0 * i + c for c in range(3)] + [float(i)] for i in range(7)], dtype=np.float32)
+    assert np.array_equal(out[0], exp) and np.array_equal(out[1], exp)
