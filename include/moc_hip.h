@@ -71,7 +71,9 @@ typedef struct moc_batch {
     uint32_t       discard_bits;
     uint32_t       reserved;
     /* ---- work arrays (device) ---- */
-    int32_t* kept;       /* [total_rows]      slot -> row index inside its slide (unused if mask==NULL) */
+    int32_t* kept;       /* [total_rows + 16] slot -> row index inside its slide (unused if mask==NULL);
+                            the 16 entries of slack let the score pass read a tile's 16 indices
+                            with one scalar load without running off the allocation            */
     int32_t* n_kept;     /* [n_slides]                                                               */
     float*   stats;      /* [2C+3, total_rows] per-slot: logits[C] | softmax[C] | gap | bg_sum | bg_max  */
     uint8_t* sel_flag;   /* [total_rows]      union membership                                        */
@@ -129,6 +131,13 @@ int    moc_prepare_bank(const float* W /*device [D,C]*/, const float* W_ext /*de
 
 /* a1  row mask -> kept list + n_kept (main_moc.py:329-331).  No-op when mask==NULL. */
 int moc_mask_compact(const moc_batch_t* B, moc_stream_t stream);
+
+/* a1, host side: the row masks of `n` consecutive rows exactly as main_moc.py:330 draws them
+ * (`torch.rand(N) > 0.5`, CPU default generator = mt19937, one output per sample).  rng_state is
+ * the byte image of torch.get_rng_state() (in/out: advanced by n draws, hand it back with
+ * torch.set_rng_state); out gets n 0/1 bytes.  Returns the number of kept rows, -1 on error.
+ * Pure host code: same bits as torch.rand, no GPU involved. */
+int64_t moc_host_draw_masks(uint8_t* rng_state, int64_t state_bytes, int64_t n, uint8_t* out);
 
 /* a2 + per-row parts of a4-a6, a9: X.[W|W_ext] and the row statistics
  * (main_moc.py:336-337, :360-365; patch_selection_classifier_index.py:34, :46-48, :75).

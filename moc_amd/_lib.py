@@ -55,6 +55,7 @@ SIGNATURES = {
     "moc_last_error": (C.c_char_p, []),
     "moc_bank_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "moc_prepare_bank": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
+    "moc_host_draw_masks": (C.c_int64, [_p, C.c_int64, C.c_int64, _p]),
     "moc_mask_compact": (C.c_int, [_BP, _p]),
     "moc_scores": (C.c_int, [_BP, _p, _p]),
     "moc_row_stats": (C.c_int, [_p, C.c_int64, C.c_int, C.c_int, _p, _p]),

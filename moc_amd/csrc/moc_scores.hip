@@ -210,6 +210,42 @@ __global__ __launch_bounds__(256) void scores_kernel(ScoresArgs a) {
     }
 }
 
+// ---- hand-counted vector loads for the streaming kernel --------------------------------
+// LDS ordering inside one wave without touching vmcnt (the workgroup-scope fence used above
+// emits s_waitcnt vmcnt(0) and would drain the loads in flight).  LDS executes a wave's
+// operations in order; only the compiler must not reorder them.
+__device__ __forceinline__ void wave_lds_order() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t;   // native vector: a legal "v" asm operand
+template <int OFF>
+__device__ __forceinline__ void asm_load16(u32x4_t& dst, const unsigned char* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
+template <int F, int NF>
+__device__ __forceinline__ void asm_issue(u32x4_t (&buf)[NF], const unsigned char* p) {
+    if constexpr (F < NF) {
+        asm_load16<F * 64>(buf[F], p);
+        asm_issue<F + 1, NF>(buf, p);
+    }
+}
+// wait until at most KEEP vector-memory operations are outstanding, then re-define every register
+// of `buf` through an empty asm so that no use of it can be scheduled above the wait
+template <int F, int NF>
+__device__ __forceinline__ void asm_touch(u32x4_t (&buf)[NF]) {
+    if constexpr (F < NF) {
+        asm volatile("" : "+v"(buf[F]));
+        asm_touch<F + 1, NF>(buf);
+    }
+}
+template <int KEEP, int NF>
+__device__ __forceinline__ void asm_wait_keep(u32x4_t (&buf)[NF]) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+    asm_touch<0, NF>(buf);
+}
+
 // ---- streaming form for Ct <= 16 (one n-tile): persistent workgroups ---------------
 // The generic kernel above leaves the load schedule to the compiler, which keeps two
 // 1-KiB loads in flight per wave (24 KB per CU: ~3 TB/s).  Here every wave walks a flat
@@ -273,27 +309,41 @@ __global__ __launch_bounds__(256, 2) void scores_stream_kernel(ScoresArgs a, int
     const int stride = gridDim.x * 4;
 
     struct Unit { const unsigned char* p; int64_t base; int row0, nk, kk0; bool last; };
+    // kept[] through the scalar cache: one tile's 16 indices are one uniform 64-B read that
+    // counts on lgkmcnt, so it never drains the vector loads in flight (constant address space:
+    // the array was written by the previous kernel and is read-only here).
+    typedef const int32_t __attribute__((address_space(4))) * kept_sptr;
+    kept_sptr kept_s = (kept_sptr)(uintptr_t)a.kept;
     auto locate = [&](int g, int ch, Unit& u) {
         int lo = 0, hi = n_slides;                 // prefix[lo] <= g < prefix[hi]
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= g) lo = mid; else hi = mid; }
-        const int b = lo;
+        const int b = __builtin_amdgcn_readfirstlane(lo);
         u.base = s_base[b];
         const int64_t xbase = s_xbase[b];
-        u.nk = s_nk[b];
-        u.row0 = (g - prefix[b]) * 16;
-        const int slot = u.row0 + (lane & 15);
-        const int slot_c = slot < u.nk ? slot : u.nk - 1;          // clamp: loads stay in bounds
-        const int r = a.kept ? a.kept[u.base + slot_c] : slot_c;
+        u.nk = __builtin_amdgcn_readfirstlane(s_nk[b]);
+        u.row0 = __builtin_amdgcn_readfirstlane((g - prefix[b]) * 16);
+        int sel = lane & 15;
+        const int last_valid = u.nk - 1 - u.row0;                  // >= 0: the tile exists
+        sel = sel < last_valid ? sel : last_valid;                 // clamp: loads stay in bounds
+        int r = u.row0 + sel;
+        if (a.kept) {
+            const int idx = __builtin_amdgcn_readfirstlane((int)u.base + u.row0);
+            int k[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                k[i] = kept_s[idx + i];
+                asm volatile("" : "+s"(k[i]));     // pin to an SGPR: keeps hipcc from folding two of
+            }                                      // them into one lane-indexed VECTOR load (vmcnt)
+            r = k[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) r = sel == i ? k[i] : r;
+        }
         u.p = a.X + (xbase + r) * row_bytes + (lane >> 4) * 16 + (int64_t)ch * NF * 64;
         u.kk0 = ch * NF;
         u.last = ch == U - 1;
     };
-    auto load = [&](uint4 (&buf)[NF], const Unit& u) {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) buf[f] = *reinterpret_cast<const uint4*>(u.p + f * 64);
-    };
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](const uint4 (&buf)[NF], const Unit& u) {
+    auto compute = [&](const u32x4_t (&buf)[NF], const Unit& u) {
         if constexpr (BF16) {
             const uint4* bp = lds_b + u.kk0 * 3 * 64 + lane;
 #pragma unroll
@@ -310,38 +360,42 @@ __global__ __launch_bounds__(256, 2) void scores_stream_kernel(ScoresArgs a, int
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const uint4 bv = bp[f * 64];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f].x), __uint_as_float(bv.x), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f].y), __uint_as_float(bv.y), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f].z), __uint_as_float(bv.z), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f].w), __uint_as_float(bv.w), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f][0]), __uint_as_float(bv.x), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f][1]), __uint_as_float(bv.y), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f][2]), __uint_as_float(bv.z), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f][3]), __uint_as_float(bv.w), acc, 0, 0, 0);
             }
         }
         if (u.last) {
-            wave_lds_sync();
+            wave_lds_order();
 #pragma unroll
             for (int i = 0; i < 4; ++i) tile[((lane >> 4) * 4 + i) * LDT + (lane & 15)] = acc[i];
-            wave_lds_sync();
+            wave_lds_order();
             if (lane < 16) row_epilogue(a, tile + lane * LDT, LDT, u.base, u.row0 + lane, u.row0 + lane < u.nk);
             acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
     };
-    // flattened (tile, unit) walk, two register buffers
+    // Flattened (tile, unit) walk, two register buffers.  The tile loads are inline asm so that the
+    // compiler's own wait insertion does not see them: it would make compute(cur) wait for ALL of
+    // the next unit's loads (vmcnt is in order; at the loop back edge hipcc assumes the worst).
+    // Instead: issue the NF loads of the next unit, then wait until only those NF are outstanding
+    // -- everything older (the current unit's loads, the previous epilogue's stores) has landed.
     int g = blockIdx.x * 4 + wave, ch = 0;
     auto advance = [&]() { if (++ch == U) { ch = 0; g += stride; } };
-    uint4 bufA[NF], bufB[NF];
+    u32x4_t bufA[NF], bufB[NF];
     Unit uA, uB;
-    if (g < total) { locate(g, ch, uA); load(bufA, uA); }
+    if (g < total) { locate(g, ch, uA); asm_issue<0, NF>(bufA, uA.p); }
     while (g < total) {
         advance();
         const bool moreB = g < total;
-        if (moreB) { locate(g, ch, uB); load(bufB, uB); }
-        __builtin_amdgcn_sched_barrier(0);
+        if (moreB) { locate(g, ch, uB); asm_issue<0, NF>(bufB, uB.p); asm_wait_keep<NF, NF>(bufA); }
+        else asm_wait_keep<0, NF>(bufA);
         compute(bufA, uA);
         if (!moreB) break;
         advance();
         const bool moreA = g < total;
-        if (moreA) { locate(g, ch, uA); load(bufA, uA); }
-        __builtin_amdgcn_sched_barrier(0);
+        if (moreA) { locate(g, ch, uA); asm_issue<0, NF>(bufA, uA.p); asm_wait_keep<NF, NF>(bufB); }
+        else asm_wait_keep<0, NF>(bufB);
         compute(bufB, uB);
     }
 }

@@ -91,7 +91,11 @@ def train_dp(model, loader, optimizer, device, args, group=None):
     from . import engine, main_moc as M
     model.train()
     X, sizes, x_starts, labels = M._collect(loader, device, args)
-    masks = [torch.rand(n) > 0.5 for n in sizes]
+    mask_all, _ = engine.draw_row_masks(sum(sizes))
+    masks, o = [], 0
+    for n in sizes:
+        masks.append(mask_all[o:o + n])
+        o += n
     bank = M._bank_for(X, device)
     meta = engine.MetaState(model, optimizer, need_grads=True)
     fg = FlatGrads(meta.params, device)

@@ -102,7 +102,7 @@ class SlideBatch:
                 self.kept_rows_host = int(mask.sum())
             self.mask = mask.to(torch.uint8).to(dev, non_blocking=True).contiguous()
         i32 = dict(dtype=torch.int32, device=dev)
-        self.kept = torch.empty(T, **i32) if mask is not None else None
+        self.kept = torch.empty(T + 16, **i32) if mask is not None else None   # +16: see moc_hip.h
         self.n_kept = torch.empty(n, **i32) if mask is not None else None
         self.stats = torch.empty((2 * self.C + 3, T), dtype=torch.float32, device=dev)
         self.sel_flag = torch.empty(T, dtype=torch.uint8, device=dev)
@@ -117,6 +117,12 @@ class SlideBatch:
             n_kept=ptr(self.n_kept), stats=ptr(self.stats), sel_flag=ptr(self.sel_flag),
             sel_idx=ptr(self.sel_idx), sel_row=ptr(self.sel_row), n_sel=ptr(self.n_sel), cand=ptr(self.cand))
         self._ws = None
+
+    def set_mask(self, host_mask_u8: torch.Tensor, kept_rows: int):
+        """New keep flags for the same visits (next epoch): async H2D into the resident mask array."""
+        assert self.mask is not None and host_mask_u8.numel() == self.total and host_mask_u8.dtype == torch.uint8
+        self.mask.copy_(host_mask_u8, non_blocking=True)
+        self.kept_rows_host = int(kept_rows)
 
     # ---- phase A ----
     def phase_a(self, bank: Bank):
@@ -212,6 +218,25 @@ class MetaState:
         for p in self.params:
             st = self.optimizer.state[p]["step"]
             st += n_steps   # tensor in-place (host or device scalar)
+
+
+def draw_row_masks(total: int, out: torch.Tensor | None = None):
+    """`total` keep flags from the CPU default generator, bit for bit what consecutive
+    `torch.rand(n_i) > 0.5` calls (sum n_i == total) produce (main_moc.py:330), leaving the generator
+    where they would.  Uses the library's mt19937 replay (several times faster than torch.rand);
+    falls back to torch.rand itself when the generator state is not the layout it knows.
+    Returns (uint8 host tensor [total], number of kept rows)."""
+    if out is None:
+        out = torch.empty(total, dtype=torch.uint8)
+    if torch.get_default_dtype() == torch.float32:
+        st = torch.get_rng_state()
+        kept = lib().moc_host_draw_masks(ptr(st), st.numel(), total, ptr(out))
+        if kept >= 0:
+            torch.set_rng_state(st)
+            return out, int(kept)
+    m = torch.rand(total) > 0.5
+    out.copy_(m)
+    return out, int(m.sum())
 
 
 def train_use_bits(discard) -> int:

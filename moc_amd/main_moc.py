@@ -115,6 +115,26 @@ class ResidentBags:
         for n in self.sizes:
             self.starts.append(self.starts[-1] + n)
         self.dataset = self
+        self._plans = {}
+
+    def train_plan(self, C_, Ce, topj, topk, discard):
+        """Work arrays, labels and pinned mask staging for train() over the current visit order,
+        built once and reused every epoch (only the mask bytes change)."""
+        order = tuple(self.visit_order())
+        key = (order, C_, Ce, topj, topk, tuple(sorted(discard or ())))
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) > 8:
+                self._plans.clear()
+            sizes = [self.sizes[k] for k in order]
+            T = sum(sizes)
+            batch = SlideBatch(self.X, sizes, C_, Ce, topj, topk, discard, mask=torch.ones(T, dtype=torch.uint8),
+                               x_starts=[self.starts[k] for k in order])
+            lab = torch.tensor([self.labels[k] for k in order], dtype=torch.int64).to(self.X.device)
+            stage = [torch.empty(T, dtype=torch.uint8).pin_memory() for _ in range(3)]
+            plan = self._plans[key] = {"batch": batch, "labels": lab, "stage": stage,
+                                       "events": [None, None, None], "turn": 0}
+        return plan
 
     def real_len(self):
         return len(self.sizes)
@@ -183,7 +203,7 @@ def slide_process(feat, zeroshot_weights, zeroshot_weights_ext,
     N = feat.size(0)
     mask = None
     if random_mask:
-        mask = torch.rand(N) > 0.5                       # CPU default generator, as the reference
+        mask, _ = engine.draw_row_masks(N)               # == torch.rand(N) > 0.5 on the CPU default generator
     C_, Ce = zeroshot_weights.size(1), zeroshot_weights_ext.size(1)
     assert C_ == n_classes, "n_classes must equal zeroshot_weights.size(1)"
     batch = SlideBatch(feat, [N], C_, Ce, topj, 1, discard_classifiers, mask=mask)
@@ -206,13 +226,37 @@ def slide_process(feat, zeroshot_weights, zeroshot_weights_ext,
 def train(model, train_loader, optimizer, device, args):
     """main_moc.py:378-410: one Adam step per slide, in loader order."""
     model.train()
+    use = engine.train_use_bits(args.discard_classifiers)
+    if isinstance(train_loader, ResidentBags):
+        # resident split: nothing is copied or allocated per epoch except the new mask bytes
+        res = train_loader
+        bank = _bank_for(res.X, device)
+        assert bank.C == args.n_classes
+        plan = res.train_plan(bank.C, bank.Ce, args.topj, args.topk, args.discard_classifiers)
+        batch, lab = plan["batch"], plan["labels"]
+        t = plan["turn"] = (plan["turn"] + 1) % len(plan["stage"])
+        if plan["events"][t] is not None:
+            plan["events"][t].synchronize()           # that staging buffer's last upload has finished
+        stage, kept = engine.draw_row_masks(batch.total, plan["stage"][t])   # main_moc.py:330, same stream of bits
+        batch.set_mask(stage, kept)
+        ev = torch.cuda.Event()
+        ev.record()
+        plan["events"][t] = ev
+        meta = MetaState(model, optimizer)
+        batch.phase_a(bank)
+        engine.train_steps(batch, meta, lab, 0, batch.n_slides, use)
+        train.last = (batch, lab)
+        return
     X, sizes, x_starts, labels = _collect(train_loader, device, args)
-    masks = [torch.rand(n) > 0.5 for n in sizes]          # main_moc.py:330, one draw per slide
+    mask_all, _ = engine.draw_row_masks(sum(sizes))      # main_moc.py:330, one draw per slide, in order
+    masks, o = [], 0
+    for n in sizes:
+        masks.append(mask_all[o:o + n])
+        o += n
     meta = MetaState(model, optimizer)
     bank = _bank_for(X, device)
     C_, Ce = bank.C, bank.Ce
     assert C_ == args.n_classes
-    use = engine.train_use_bits(args.discard_classifiers)
     for ids in _chunks(sizes, X.size(1), X.element_size()):
         batch = _sub_batch(X, sizes, x_starts, ids, C_, Ce, args.topj, args.topk, args.discard_classifiers, masks)
         lab = torch.tensor([labels[i] for i in ids], dtype=torch.int64).to(device, non_blocking=True)

@@ -1,0 +1,58 @@
+"""The library's host-side mask generator must reproduce torch's CPU generator bit for bit
+(main_moc.py:330 draws `torch.rand(N) > 0.5` there) and leave it in the same state."""
+import torch
+
+from moc_amd import engine
+
+
+def _positions():
+    for seed in (0, 1, 123, 99999, 2 ** 31 + 5):
+        for pre in (0, 1, 623, 624, 625, 1000):
+            yield seed, pre
+
+
+def test_masks_equal_torch_rand_stream():
+    for seed, pre in _positions():
+        sizes = [5, 619, 1, 1, 3, 624, 625, 1247, 15000, 7]
+        torch.manual_seed(seed)
+        torch.rand(pre)
+        ref = [torch.rand(n) > 0.5 for n in sizes]
+        after_ref = torch.rand(4)
+        torch.manual_seed(seed)
+        torch.rand(pre)
+        got = [engine.draw_row_masks(n) for n in sizes]
+        after = torch.rand(4)
+        for r, (g, k) in zip(ref, got):
+            assert g.dtype == torch.uint8 and torch.equal(r, g.bool()) and int(r.sum()) == k
+        assert torch.equal(after_ref, after), "generator left in a different state than torch.rand would"
+
+
+def test_one_call_equals_per_slide_calls():
+    sizes = [15000, 14321, 9, 60000, 2000]
+    torch.manual_seed(42)
+    ref = torch.cat([torch.rand(n) > 0.5 for n in sizes])
+    torch.manual_seed(42)
+    allm, kept = engine.draw_row_masks(sum(sizes))
+    assert torch.equal(ref, allm.bool()) and kept == int(ref.sum())
+
+
+def test_other_draws_interleave_correctly():
+    torch.manual_seed(7)
+    a1, n1, a2 = torch.rand(10) > 0.5, torch.randn(5), torch.rand(700) > 0.5
+    torch.manual_seed(7)
+    b1, _ = engine.draw_row_masks(10)
+    m1 = torch.randn(5)
+    b2, _ = engine.draw_row_masks(700)
+    assert torch.equal(a1, b1.bool()) and torch.equal(n1, m1) and torch.equal(a2, b2.bool())
+
+
+def test_falls_back_under_float64_default():
+    torch.set_default_dtype(torch.float64)
+    try:
+        torch.manual_seed(3)
+        ref = torch.rand(100) > 0.5
+        torch.manual_seed(3)
+        got, _ = engine.draw_row_masks(100)
+        assert torch.equal(ref, got.bool())
+    finally:
+        torch.set_default_dtype(torch.float32)
