@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 1
+#define MOC_ABI_VERSION 3
 
 enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
 
@@ -58,6 +58,9 @@ typedef struct moc_batch {
     int32_t        max_rows;   /* max rows of any slide (host value, sizes the grids)    */
     const int64_t* row_off;    /* device [n_slides+1], first SLOT of each slide (prefix
                                   sum of the slide sizes)                                */
+    const int64_t* row_off_host; /* host copy of row_off, or NULL.  With it, single-slide launches
+                                  (the sequential train steps) get the slide's first slot as a
+                                  kernel argument instead of a dependent device load          */
     const int64_t* x_off;      /* device [n_slides], first row of each slide inside X, or
                                   NULL = row_off (slides packed in batch order).  Lets a
                                   batch visit resident slides in any order / repeatedly
@@ -90,6 +93,10 @@ typedef struct moc_meta {
     float *m_W1, *m_b1, *m_W2, *m_b2; /* exp_avg      (may be NULL for forward-only use)   */
     float *v_W1, *v_b1, *v_W2, *v_b2; /* exp_avg_sq                                        */
     float *g_W1, *g_b1, *g_W2, *g_b2; /* gradient outputs (moc_train_grad), may be NULL    */
+    void  *W1_image;                  /* device scratch, moc_w1_image_bytes(D, dtype): W1 re-laid in
+                                         MFMA operand order for the forward pass.  Derived data the
+                                         library rebuilds / keeps in sync itself; contents need not
+                                         survive between calls.                                */
     double lr, beta1, beta2, eps, weight_decay; /* the optimizer's Python floats, unrounded     */
     int32_t H;                        /* hidden width, must be 64                          */
     int32_t D;                        /* input width (== batch D)                          */
@@ -107,12 +114,14 @@ typedef struct moc_meta_ws {
     float*   loss;      /* [n_slides]       cross entropy                                    */
     int32_t* pred;      /* [n_slides]       argmax of pooled                                 */
     float*   pair_dh;   /* [C*topk, H]      backward scratch (one slide at a time)           */
+    float*   pair_x;    /* [C*topk, D]      the pairs' bag rows as fp32 (gathered once per step)    */
     int64_t* pair_row;  /* [C*topk]                                                          */
     int32_t* n_pair;    /* [1]                                                               */
 } moc_meta_ws_t;
 
 int         moc_version(void);
 const char* moc_last_error(void);
+size_t      moc_w1_image_bytes(int D, int dtype);
 
 /* ---- classifier bank ------------------------------------------------------
  * Re-lays [zeroshot_weights | zeroshot_weights_ext[:, C:]] (main_moc.py:336-337:

@@ -14,8 +14,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmoc_hip.so")
-ABI_VERSION = 1
+LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
+ABI_VERSION = 3
 
 MOC_F32, MOC_BF16 = 0, 1
 SEL_BITS = {"topk": 1, "delta_softmax": 2, "delta_diff": 4, "bottomk": 8}
@@ -26,7 +26,7 @@ _p = C.c_void_p
 class MocBatch(C.Structure):
     _fields_ = [
         ("X", _p), ("dtype", C.c_int32), ("D", C.c_int32), ("total_rows", C.c_int64),
-        ("n_slides", C.c_int32), ("max_rows", C.c_int32), ("row_off", _p), ("x_off", _p), ("mask", _p),
+        ("n_slides", C.c_int32), ("max_rows", C.c_int32), ("row_off", _p), ("row_off_host", _p), ("x_off", _p), ("mask", _p),
         ("C", C.c_int32), ("Ce", C.c_int32), ("topj", C.c_int32), ("topk", C.c_int32),
         ("discard_bits", C.c_uint32), ("reserved", C.c_uint32),
         ("kept", _p), ("n_kept", _p), ("stats", _p), ("sel_flag", _p), ("sel_idx", _p),
@@ -37,7 +37,7 @@ class MocBatch(C.Structure):
 class MocMeta(C.Structure):
     _fields_ = (
         [(n, _p) for n in ("W1", "b1", "W2", "b2", "m_W1", "m_b1", "m_W2", "m_b2",
-                           "v_W1", "v_b1", "v_W2", "v_b2", "g_W1", "g_b1", "g_W2", "g_b2")]
+                           "v_W1", "v_b1", "v_W2", "v_b2", "g_W1", "g_b1", "g_W2", "g_b2", "W1_image")]
         + [(n, C.c_double) for n in ("lr", "beta1", "beta2", "eps", "weight_decay")]
         + [("H", C.c_int32), ("D", C.c_int32), ("step", C.c_int64)]
     )
@@ -45,7 +45,7 @@ class MocMeta(C.Structure):
 
 class MocMetaWs(C.Structure):
     _fields_ = [(n, _p) for n in ("H1", "gates", "mixed", "pooled", "topk_idx", "topk_cnt",
-                                  "loss", "pred", "pair_dh", "pair_row", "n_pair")]
+                                  "loss", "pred", "pair_dh", "pair_x", "pair_row", "n_pair")]
 
 
 # name -> (restype, argtypes); every symbol include/moc_hip.h declares
@@ -54,6 +54,7 @@ SIGNATURES = {
     "moc_version": (C.c_int, []),
     "moc_last_error": (C.c_char_p, []),
     "moc_bank_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "moc_w1_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "moc_prepare_bank": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "moc_host_draw_masks": (C.c_int64, [_p, C.c_int64, C.c_int64, _p]),
     "moc_mask_compact": (C.c_int, [_BP, _p]),

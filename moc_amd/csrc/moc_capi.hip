@@ -21,3 +21,10 @@ extern "C" int moc_phase_a(const moc_batch_t* B, const void* bank, moc_stream_t 
     if (int rc = moc_select(B, stream)) return rc;
     return moc_gather_candidates(B, nullptr, stream);
 }
+
+#ifdef MOC_STAMPS
+__device__ unsigned long long g_moc_stamps[128];
+extern "C" int moc_debug_stamps(unsigned long long* host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_moc_stamps), sizeof(unsigned long long) * n);
+}
+#endif

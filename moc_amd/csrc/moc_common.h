@@ -67,3 +67,18 @@ __device__ __forceinline__ int moc_block_flag_scan(bool flag, int* wave_tot, int
     *block_total = tot;
     return off + before;
 }
+
+// ---- diagnostic build only (-DMOC_STAMPS, make stamps): constant-clock (100 MHz) time stamps of
+// kernel phases, written by thread 0 of workgroup (0,0) to a global array that nothing else reads.
+#ifdef MOC_STAMPS
+extern __device__ unsigned long long g_moc_stamps[128];
+#define MOC_STAMP(id)                                                                          \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {                            \
+            g_moc_stamps[id] = wall_clock64();                                                 \
+            g_moc_stamps[64 + (id)] = __builtin_amdgcn_s_memtime();   /* shader cycles */       \
+        }                                                                                      \
+    } while (0)
+#else
+#define MOC_STAMP(id) do { } while (0)
+#endif

@@ -55,106 +55,154 @@ struct FwdArgs {
     const int32_t* n_sel;
     const float* cand;
     const float *W1, *b1, *W2, *b2;
+    const unsigned char* W1img;     // W1 in MFMA B-operand order (see w1_image_* below)
     float *H1, *gates, *mixed;
     int64_t stride;
+    int64_t base_host;              // >= 0: first slot of the (single) slide, known to the host
     int D, C, slide0;
     uint32_t use_bits;
 };
 
+// ---- W1 image ----------------------------------------------------------------------------
+// The forward's B operand is W1^T: B[k][n] = W1[n][k].  Read from the [H][D] parameter tensor,
+// a wave's fragment load touches 64 scattered 16-B pieces (16 rows 2 KB apart) and the address
+// unit, not HBM, sets the pace.  So the kernels keep a second copy in fragment order -- one
+// contiguous 1 KiB per wave-load -- rewritten by the W1 update itself, hence always in sync:
+//   bf16 bags: [nt][kk][term][lane][8] bf16, element j of lane l = term t of W1[nt*16 + (l&15)][kk*32 + (l>>4)*8 + j]
+//              (hi/mid/lo split, 24 mantissa bits: bf16 MFMA with fp32-exact products)
+//   fp32 bags: [nt][kq][lane][4] f32,         element m of lane l = W1[nt*16 + (l&15)][kq*16 + (l>>4)*4 + m]
+__device__ __forceinline__ void w1_image_store_bf16(unsigned char* img, int D, int h, int d, float w) {
+    const int KK = D / 32;
+    const int nt = h >> 4, kk = d >> 5, lane = (((d & 31) >> 3) << 4) | (h & 15), j = d & 7;
+    uint16_t* o = reinterpret_cast<uint16_t*>(img) + ((size_t)(nt * KK + kk) * 3 * 64 + lane) * 8 + j;
+    const uint16_t hi = moc_f32_to_bf16_rne(w);
+    const float r1 = w - moc_bf16_to_f32(hi);
+    const uint16_t mid = moc_f32_to_bf16_rne(r1);
+    const uint16_t lo = moc_f32_to_bf16_rne(r1 - moc_bf16_to_f32(mid));
+    o[0] = hi;
+    o[64 * 8] = mid;
+    o[2 * 64 * 8] = lo;
+}
+__device__ __forceinline__ void w1_image_store_f32(unsigned char* img, int D, int h, int d, float w) {
+    const int KQ = D / 16;
+    const int nt = h >> 4, kq = d >> 4, lane = (((d & 15) >> 2) << 4) | (h & 15), m = d & 3;
+    reinterpret_cast<float*>(img)[((size_t)(nt * KQ + kq) * 64 + lane) * 4 + m] = w;
+}
+template <bool BF16>
+__global__ __launch_bounds__(256) void w1_image_kernel(const float* W1, int D, unsigned char* img) {
+    const int e = blockIdx.x * 256 + threadIdx.x;       // grid = H*D/256
+    const int h = e / D, d = e - h * D;
+    if constexpr (BF16) w1_image_store_bf16(img, D, h, d, W1[e]);
+    else w1_image_store_f32(img, D, h, d, W1[e]);
+}
+
 // grid (ceil(S_bound/16), n): one workgroup = 16 selected rows, wave w = hidden units 16w..16w+15.
 template <bool BF16>
 __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
+    __shared__ __attribute__((aligned(16))) uint4 xt[16 * 64];     // 16 rows x 1 KiB, chunk-swizzled
     __shared__ float Hs[16][H + 1];
     __shared__ float Gs[16][4];
+    __shared__ float W2s[4 * H];
     const int b = a.slide0 + blockIdx.y;
-    const int64_t base = a.row_off[b];
+    const int64_t base = a.base_host >= 0 ? a.base_host : a.row_off[b];
     const int S = a.n_sel[b];
     const int row0 = blockIdx.x * 16;
     if (row0 >= S) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int ESZ = BF16 ? 2 : 4;
-    const int s_c = min(row0 + (lane & 15), S - 1);
-    const unsigned char* xp = a.X + a.sel_row[base + s_c] * (int64_t)a.D * ESZ + (lane >> 4) * 16;
-    const float* wp = a.W1 + (int64_t)(wave * 16 + (lane & 15)) * a.D;
+    MOC_STAMP(0);
+    // Epilogue operands that do not depend on the product are requested first.
+    const int C = a.C;
+    float pre_c[4] = {0.f, 0.f, 0.f, 0.f};
+    if (threadIdx.x < 16 * C && row0 + (threadIdx.x & 15) < S) {
+        const int r = threadIdx.x & 15, c = threadIdx.x >> 4;
+        const float* cd = a.cand + base + row0 + r;
+        pre_c[0] = cd[(int64_t)c * a.stride];
+        pre_c[1] = cd[(int64_t)(C + c) * a.stride];
+        pre_c[2] = cd[(int64_t)(2 * C) * a.stride];
+        pre_c[3] = cd[(int64_t)(2 * C + 1) * a.stride];
+    }
+    const float w2_pre = a.W2[threadIdx.x & 255];
+    const float bias = a.b1[wave * 16 + (lane & 15)];
+    const float b2_pre = a.b2[threadIdx.x & 3];
+    // The 16 x D tile of x goes through LDS once per workgroup: wave w fetches rows 4w..4w+3 with
+    // whole-row contiguous loads (UB bytes per row per unit) and stores 16-B chunk c of row r at
+    // chunk c ^ (r & 15), so that the A-fragment reads (lane l: row l&15, chunk 4*kk + (l>>4)) hit
+    // distinct banks.  W1 comes from its fragment-ordered image: one contiguous 1 KiB per load.
+    const int64_t row_bytes = (int64_t)a.D * ESZ;
+    const int UB = (row_bytes % 1024 == 0) ? 1024 : 512;          // bytes of a row per unit
+    const int U = (int)(row_bytes / UB), cpr = UB / 16;           // units, 16-B chunks per row per unit
+    const int ksteps = UB / 64;                                   // MFMA k-steps (bf16: 32 el, f32: 16 el) per unit
+    const unsigned char* rp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int sr = min(row0 + wave * 4 + i, S - 1);
+        rp[i] = a.X + a.sel_row[base + sr] * row_bytes;
+    }
+    const int KST = (int)(row_bytes / 64);                        // k-steps over all of D
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    // K is walked in chunks of 128 elements: the chunk's x fragments and W1 fragments are all
-    // requested before the first MFMA of the chunk (sched_barrier keeps hipcc from re-serialising
-    // them), and the next chunk's loads are issued while this chunk's MFMAs run.
-    if constexpr (BF16) {
-        // 16 B of x = 8 bf16 = k offsets kk*32 + (lane>>4)*8 + j; W1 row read at the same k
-        constexpr int G = 4;                       // k-steps of 32 per chunk
-        const int nchunk = a.D / (32 * G);
-        uint4 xa[G], xb[G];
-        float4 wa[2 * G], wb[2 * G];
-        auto ld = [&](uint4 (&xv)[G], float4 (&wv)[2 * G], int ch) {
+    for (int u = 0; u < U; ++u) {
+        if (u > 0) __syncthreads();                               // every wave is done reading the previous tile
+        uint4 xv[4];
+        const int xc = lane < cpr ? lane : 0;                     // lanes past the unit re-read chunk 0 (not stored)
 #pragma unroll
-            for (int q = 0; q < G; ++q) {
-                const int kk = ch * G + q;
-                xv[q] = *reinterpret_cast<const uint4*>(xp + kk * 64);
-                wv[2 * q] = *reinterpret_cast<const float4*>(wp + kk * 32 + (lane >> 4) * 8);
-                wv[2 * q + 1] = *reinterpret_cast<const float4*>(wp + kk * 32 + (lane >> 4) * 8 + 4);
-            }
-        };
-        auto mm = [&](const uint4 (&xv)[G], const float4 (&wv)[2 * G]) {
+        for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const uint4*>(rp[i] + (int64_t)u * UB + xc * 16);
+        if constexpr (BF16) {
+            // this unit's W1 image: 16 (or 8) k-steps x 3 terms, all requested before the first MFMA
+            uint4 wv[16 * 3];
+            const uint4* wi = reinterpret_cast<const uint4*>(a.W1img) + ((size_t)wave * KST + (size_t)u * ksteps) * 3 * 64 + lane;
 #pragma unroll
-            for (int q = 0; q < G; ++q) {
-                const uint32_t xs[4] = {xv[q].x, xv[q].y, xv[q].z, xv[q].w};
-                const float ws[8] = {wv[2 * q].x, wv[2 * q].y, wv[2 * q].z, wv[2 * q].w,
-                                     wv[2 * q + 1].x, wv[2 * q + 1].y, wv[2 * q + 1].z, wv[2 * q + 1].w};
+            for (int q = 0; q < 16 * 3; ++q) if (q < ksteps * 3) wv[q] = wi[q * 64];
+            if (lane < cpr) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xs[j] << 16), ws[2 * j], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xs[j] & 0xFFFF0000u), ws[2 * j + 1], acc, 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    const int r = wave * 4 + i;
+                    xt[r * 64 + (lane ^ (r & 15))] = xv[i];
                 }
             }
-        };
-        ld(xa, wa, 0);
-        for (int ch = 0; ch < nchunk; ch += 2) {
-            if (ch + 1 < nchunk) ld(xb, wb, ch + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(xa, wa);
-            if (ch + 1 >= nchunk) break;
-            if (ch + 2 < nchunk) ld(xa, wa, ch + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(xb, wb);
-        }
-    } else {
-        constexpr int G = 8;                       // k-steps of 16 per chunk
-        const int nchunk = a.D / (16 * G);
-        float4 xa[G], xb[G], wa[G], wb[G];
-        auto ld = [&](float4 (&xv)[G], float4 (&wv)[G], int ch) {
+            __syncthreads();
 #pragma unroll
-            for (int q = 0; q < G; ++q) {
-                const int kq = ch * G + q;
-                xv[q] = *reinterpret_cast<const float4*>(xp + kq * 64);
-                wv[q] = *reinterpret_cast<const float4*>(wp + kq * 16 + (lane >> 4) * 4);
-            }
-        };
-        auto mm = [&](const float4 (&xv)[G], const float4 (&wv)[G]) {
+            for (int kk = 0; kk < 16; ++kk) {
+                if (kk < ksteps) {
+                    const int r = lane & 15;
+                    const bf16x8_t A = __builtin_bit_cast(bf16x8_t, xt[r * 64 + ((kk * 4 + (lane >> 4)) ^ r)]);
 #pragma unroll
-            for (int q = 0; q < G; ++q) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[q].x, wv[q].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[q].y, wv[q].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[q].z, wv[q].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[q].w, wv[q].w, acc, 0, 0, 0);
+                    for (int t = 0; t < 3; ++t)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, __builtin_bit_cast(bf16x8_t, wv[kk * 3 + t]), acc, 0, 0, 0);
+                }
             }
-        };
-        ld(xa, wa, 0);
-        for (int ch = 0; ch < nchunk; ch += 2) {
-            if (ch + 1 < nchunk) ld(xb, wb, ch + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(xa, wa);
-            if (ch + 1 >= nchunk) break;
-            if (ch + 2 < nchunk) ld(xa, wa, ch + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(xb, wb);
+        } else {
+            uint4 wv[16];
+            const uint4* wi = reinterpret_cast<const uint4*>(a.W1img) + ((size_t)wave * KST + (size_t)u * ksteps) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) if (q < ksteps) wv[q] = wi[q * 64];
+            if (lane < cpr) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = wave * 4 + i;
+                    xt[r * 64 + (lane ^ (r & 15))] = xv[i];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kq = 0; kq < 16; ++kq) {
+                if (kq < ksteps) {
+                    const int r = lane & 15;
+                    const uint4 xa = xt[r * 64 + ((kq * 4 + (lane >> 4)) ^ r)];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa.x), __uint_as_float(wv[kq].x), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa.y), __uint_as_float(wv[kq].y), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa.z), __uint_as_float(wv[kq].z), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa.w), __uint_as_float(wv[kq].w), acc, 0, 0, 0);
+                }
+            }
         }
     }
+    MOC_STAMP(1);
     {   // acc[i] = pre-activation of row (lane>>4)*4+i, hidden unit wave*16 + (lane&15)
         const int hcol = wave * 16 + (lane & 15);
-        const float bias = a.b1[hcol];
 #pragma unroll
         for (int i = 0; i < 4; ++i) Hs[(lane >> 4) * 4 + i][hcol] = fmaxf(__fadd_rn(acc[i], bias), 0.f);
+        W2s[threadIdx.x] = w2_pre;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 16 * H; e += 256) {
@@ -164,20 +212,22 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
     if (threadIdx.x < 64) {
         const int r = threadIdx.x >> 2, i = threadIdx.x & 3;
         float z = 0.f;
-        for (int h = 0; h < H; ++h) z = fmaf(Hs[r][h], a.W2[i * H + h], z);
-        z += a.b2[i];
+        for (int h = 0; h < H; ++h) z = fmaf(Hs[r][h], W2s[i * H + h], z);
+        z += b2_pre;
         const float g = 1.f / (1.f + expf(-z));
         Gs[r][i] = g;
         if (row0 + r < S) a.gates[(base + row0 + r) * 4 + i] = g;
     }
     __syncthreads();
-    const int C = a.C;
     for (int e = threadIdx.x; e < 16 * C; e += 256) {
         const int r = e & 15, c = e >> 4;
         if (row0 + r >= S) continue;
-        const float* cd = a.cand + base + row0 + r;
-        const float s0 = cd[(int64_t)c * a.stride], s1 = cd[(int64_t)(C + c) * a.stride];
-        const float s2 = cd[(int64_t)(2 * C) * a.stride], s3 = cd[(int64_t)(2 * C + 1) * a.stride];
+        float s0 = pre_c[0], s1 = pre_c[1], s2 = pre_c[2], s3 = pre_c[3];
+        if (e >= 256) {   // C > 16: beyond the prefetched element
+            const float* cd = a.cand + base + row0 + r;
+            s0 = cd[(int64_t)c * a.stride]; s1 = cd[(int64_t)(C + c) * a.stride];
+            s2 = cd[(int64_t)(2 * C) * a.stride]; s3 = cd[(int64_t)(2 * C + 1) * a.stride];
+        }
         float v = 0.f;   // 0 + x == x exactly, so this is the reference's running sum in both modes
         if (a.use_bits & 1u) v = __fadd_rn(v, __fmul_rn(Gs[r][0], s0));
         if (a.use_bits & 2u) v = __fadd_rn(v, __fmul_rn(Gs[r][1], s1));
@@ -185,6 +235,7 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
         if (a.use_bits & 8u) v = __fadd_rn(v, __fmul_rn(Gs[r][3], s3));
         a.mixed[(int64_t)c * a.stride + base + row0 + r] = v;
     }
+    MOC_STAMP(2);
 }
 
 // ablation mixes (main_moc.py:538-553): grid (ceil(S_bound/256), n), thread -> selected row
@@ -223,9 +274,13 @@ struct FinishArgs {
     float *m_W2, *m_b2, *m_b1, *v_W2, *v_b2, *v_b1;
     float *g_W2, *g_b2, *g_b1;
     float* pair_dh;
+    float* pair_x;                  // fused kernel: [C*K][D] fp32 rows of the pairs
+    const unsigned char* X;
     int64_t* pair_row;
     int32_t* n_pair;
     int64_t stride;
+    int64_t base_host;              // >= 0: first slot of the (single) slide; seg_host its slot count
+    int seg_host, D, bf16;
     int C, K, slide0, train, apply_adam;
     uint32_t use_bits;
     AdamCoef adam;
@@ -320,7 +375,7 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
 // They go to a short LDS list per class, and one wave per class extracts them in value order
 // (K wave-wide max reductions over the short list, DPP row operations, no LDS round trips).
 constexpr int PS_VPT = 4;       // values per thread per class  (S <= 4096)
-constexpr int PS_CAP = 512;     // candidate list entries per class
+constexpr int PS_CAP_MAX = 1024; // candidate list entries per class (the launch picks cap <= this)
 
 // inclusive max-scan by DPP row shifts, then the wave total from lane 63 (gfx9 DPP controls:
 // row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143)
@@ -346,19 +401,15 @@ __device__ __forceinline__ float key_to_float(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
-// element e of thread (wave, lane): position i = (q*64 + lane)*16 + wave
 __device__ __forceinline__ unsigned long long ps_key(const float* col, int i, int S) {
     return i < S ? ((unsigned long long)moc_key_desc(col[i]) << 32) | (unsigned)(~(unsigned)i) : 0ull;
 }
 
 // grid (n): one workgroup (1024 threads) per slide
 __global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* pooled_out, int32_t* topk_idx_out,
-                                                         int32_t* topk_cnt_out) {
+                                                         int32_t* topk_cnt_out, int PS_CAP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = a.slide0 + blockIdx.x, C = a.C, K = a.K;
-    const int64_t base = a.row_off[b];
-    const int S = a.n_sel[b];
-    const int k = K < S ? K : S;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // LDS carve (all dynamic)
     unsigned long long* list = reinterpret_cast<unsigned long long*>(smem);          // [C][PS_CAP]
@@ -368,35 +419,70 @@ __global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* po
     int* ncand = reinterpret_cast<int*>(dpool + C);                                  // [C]
     int* topk_s = ncand + C;                                                         // [C][K]
     float* dz = reinterpret_cast<float*>(topk_s + C * K);                            // [P][4]   (train)
-    int* prow = reinterpret_cast<int*>(dz + (size_t)C * K * 4);                      // [P]
-    float* H1s = reinterpret_cast<float*>(prow + C * K);                             // [P][H]
+    float* H1s = dz + (size_t)C * K * 4;                                             // [P][H]
     float* dhs = H1s + (size_t)C * K * H;                                            // [P][H]
     float* W2s = dhs + (size_t)C * K * H;                                            // [4][H]
-
-    if (threadIdx.x < C) ncand[threadIdx.x] = 0;
-    if (k > 0) {
-        // ---- per-wave maxima
-        for (int c = 0; c < C; ++c) {
-            const float* col = a.mixed_in + (int64_t)c * a.stride + base;
-            unsigned long long m = 0;
-#pragma unroll
-            for (int q = 0; q < PS_VPT; ++q) {
-                const unsigned long long v = ps_key(col, (q * 64 + lane) * 16 + wave, S);
-                m = v > m ? v : m;
-            }
-            m = wave_max_u64(m);
-            if (lane == 0) wmax[c * 16 + wave] = m;
-        }
+    MOC_STAMP(10);
+    // operands that do not depend on this slide's scores: requested first, consumed last
+    float pW = 0.f, pM = 0.f, pV = 0.f;       // parameter / exp_avg / exp_avg_sq this thread will step
+    if (a.train) {
+        const int t = threadIdx.x;
+        if (t < 4 * H) { W2s[t] = pW = a.W2[t]; if (a.apply_adam) { pM = a.m_W2[t]; pV = a.v_W2[t]; } }
+        else if (t < 4 * H + 4) { pW = a.b2[t - 4 * H]; if (a.apply_adam) { pM = a.m_b2[t - 4 * H]; pV = a.v_b2[t - 4 * H]; } }
+        else if (t >= 320 && t < 320 + H) { pW = a.b1[t - 320]; if (a.apply_adam) { pM = a.m_b1[t - 320]; pV = a.v_b1[t - 320]; } }
     }
-    __syncthreads();
-    if (k > 0) {
-        // ---- threshold + candidates
-        for (int c = 0; c < C; ++c) {
+    const int64_t base = a.base_host >= 0 ? a.base_host : a.row_off[b];
+    const int seg = a.base_host >= 0 ? a.seg_host : (int)(a.row_off[b + 1] - base);   // reads below stay inside the slide's slots
+    const int y = (int)a.labels[b];
+    if (threadIdx.x < C) ncand[threadIdx.x] = 0;
+    // ---- the mixed scores, once: element q*1024 + tid (contiguous per wave) of up to 4 classes at a
+    // time.  The loads are issued before n_sel is known (clamped to the slide's slots), masked after.
+    // With fewer than k non-empty waves (S < 64k) the threshold below is 0 and every element is a
+    // candidate: S <= 64*15 then, which the list holds.
+    const int S = a.n_sel[b];
+    const int k = K < S ? K : S;
+    for (int c0 = 0; c0 < C; c0 += 4) {
+        unsigned long long key[4][PS_VPT];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+            for (int q = 0; q < PS_VPT; ++q) key[cc][q] = 0ull;
+            if (c0 + cc < C) {                                   // uniform: no work for absent classes
+                const float* col = a.mixed_in + (int64_t)(c0 + cc) * a.stride + base;
+                float v[PS_VPT];
+#pragma unroll
+                for (int q = 0; q < PS_VPT; ++q) {
+                    const int i = q * 1024 + (int)threadIdx.x;
+                    v[q] = col[i < seg ? i : seg - 1];
+                }
+#pragma unroll
+                for (int q = 0; q < PS_VPT; ++q) {
+                    const int i = q * 1024 + (int)threadIdx.x;
+                    key[cc][q] = i < S ? ((unsigned long long)moc_key_desc(v[q]) << 32) | (unsigned)(~(unsigned)i) : 0ull;
+                }
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            if (c0 + cc < C) {
+                unsigned long long m = 0;
+#pragma unroll
+                for (int q = 0; q < PS_VPT; ++q) m = key[cc][q] > m ? key[cc][q] : m;
+                m = wave_max_u64(m);
+                if (lane == 0) wmax[(c0 + cc) * 16 + wave] = m;
+            }
+        }
+        __syncthreads();
+        MOC_STAMP(11);
+        // threshold = K-th largest wave maximum (keys are unique; 0 = empty wave), then candidates
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = c0 + cc;
+            if (c >= C) break;
             const unsigned long long mine = wmax[c * 16 + (lane & 15)];
             int rank = 0;
 #pragma unroll
             for (int l = 0; l < 16; ++l) rank += wmax[c * 16 + l] > mine ? 1 : 0;
-            // K-th largest wave maximum (keys are unique; zero = empty wave)
             const unsigned long long hit = __ballot(lane < 16 && rank == k - 1 && mine != 0ull);
             unsigned long long T0 = 0ull;
             if (hit != 0ull && k <= 16) {
@@ -405,10 +491,9 @@ __global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* po
                 const unsigned hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), src, 64);
                 T0 = ((unsigned long long)hi << 32) | lo;
             }
-            const float* col = a.mixed_in + (int64_t)c * a.stride + base;
 #pragma unroll
             for (int q = 0; q < PS_VPT; ++q) {
-                const unsigned long long v = ps_key(col, (q * 64 + lane) * 16 + wave, S);
+                const unsigned long long v = key[cc][q];
                 if (v != 0ull && v >= T0) {
                     const int pos = atomicAdd(&ncand[c], 1);
                     if (pos < PS_CAP) list[(size_t)c * PS_CAP + pos] = v;
@@ -417,14 +502,33 @@ __global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* po
         }
     }
     __syncthreads();
-    // ---- extraction: wave w takes classes w, w+16, ...
+    MOC_STAMP(12);
+    // ---- extraction: wave w takes classes w, w+16, ...  Short lists (<= 64 candidates, the normal
+    // case) are ranked in one sweep: a candidate's rank is the number of larger ones, and rank r < k
+    // IS its position in value order.  Longer lists fall back to k wave-wide maximum rounds.
     for (int c = wave; c < C; c += 16) {
-        float sum = 0.f;
-        if (k > 0) {
-            const int n = ncand[c];
+        const int n = ncand[c];
+        if (k > 0 && n <= 64) {
+            const unsigned long long mine = lane < n ? list[(size_t)c * PS_CAP + lane] : 0ull;
+            int rank = 0;
+            for (int l = 0; l < n; ++l) rank += list[(size_t)c * PS_CAP + l] > mine ? 1 : 0;
+            float* topv = reinterpret_cast<float*>(wmax + c * 16);       // wave maxima are spent: 16 x 8 B of scratch
+            if (lane < n && rank < k) {
+                topk_s[c * K + rank] = (int)(~(unsigned)mine);
+                topv[rank] = key_to_float((unsigned)(mine >> 32));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {                                             // summed largest first
+                float sum = 0.f;
+                for (int r = 0; r < k; ++r) sum += topv[r];
+                pooled_s[c] = sum / (float)k;
+            }
+        } else if (k > 0) {
             const bool overflow = n > PS_CAP;        // pathological ties: rank straight from global
             const float* col = a.mixed_in + (int64_t)c * a.stride + base;
             unsigned long long prev = ~0ull;
+            float sum = 0.f;
             for (int r = 0; r < k; ++r) {
                 unsigned long long best = 0ull;
                 if (!overflow) {
@@ -440,14 +544,16 @@ __global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* po
                 }
                 best = wave_max_u64(best);
                 prev = best;
-                sum += key_to_float((unsigned)(best >> 32));           // value order: largest first
+                sum += key_to_float((unsigned)(best >> 32));
                 if (lane == 0) topk_s[c * K + r] = (int)(~(unsigned)best);
             }
+            if (lane == 0) pooled_s[c] = sum / (float)k;
+        } else if (lane == 0) {
+            pooled_s[c] = __uint_as_float(0x7FC00000u);     // mean over no rows = NaN, like torch
         }
+        __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
-            const float pv = k > 0 ? sum / (float)k : __uint_as_float(0x7FC00000u);   // empty mean = NaN
-            pooled_s[c] = pv;
-            pooled_out[(int64_t)b * C + c] = pv;
+            pooled_out[(int64_t)b * C + c] = pooled_s[c];
             if (topk_cnt_out) topk_cnt_out[(int64_t)b * C + c] = k;
         }
         if (topk_idx_out)
@@ -455,47 +561,76 @@ __global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* po
                 topk_idx_out[((int64_t)b * C + c) * K + r] = r < k ? topk_s[c * K + r] : -1;
     }
     __syncthreads();
-    // ---- cross entropy, argmax
-    const int y = (int)a.labels[b];
-    if (threadIdx.x == 0) {
-        float mx = -INFINITY;
-        int arg = 0;
-        for (int c = 0; c < C; ++c) if (pooled_s[c] > mx) { mx = pooled_s[c]; arg = c; }
-        float se = 0.f;
-        for (int c = 0; c < C; ++c) se += expf(pooled_s[c] - mx);
-        const float lse = mx + logf(se);
-        a.loss[b] = lse - pooled_s[y];
-        a.pred[b] = arg;
-        if (a.train) for (int c = 0; c < C; ++c) dpool[c] = expf(pooled_s[c] - lse) - (c == y ? 1.f : 0.f);
-    }
-    if (!a.train) return;
-    for (int e = threadIdx.x; e < 4 * H; e += 1024) W2s[e] = a.W2[e];
-    __syncthreads();
-    // ---- pairs p = (class c, r-th pooled row): dz, gathered H1 rows
-    const int P = C * k;
-    for (int p = threadIdx.x; p < P; p += 1024) {
-        const int c = p / k, r = p - c * k;
-        const int sidx = topk_s[c * K + r];
-        prow[p] = sidx;
-        const float g = dpool[c] / (float)k;
-        const float* cd = a.cand + base + sidx;
-        const float sc[4] = {cd[(int64_t)c * a.stride], cd[(int64_t)(C + c) * a.stride],
-                             cd[(int64_t)(2 * C) * a.stride], cd[(int64_t)(2 * C + 1) * a.stride]};
-        const float4 lam4 = *reinterpret_cast<const float4*>(a.gates + (base + sidx) * 4);
-        const float lam[4] = {lam4.x, lam4.y, lam4.z, lam4.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float dlam = (a.use_bits >> i & 1u) ? g * sc[i] : 0.f;
-            dz[p * 4 + i] = dlam * lam[i] * (1.f - lam[i]);
+    MOC_STAMP(13);
+    // ---- cross entropy, argmax: wave 0, one class per lane (C <= 16)
+    if (wave == 0) {
+        const float xv = lane < C ? pooled_s[lane] : -INFINITY;
+        float mx = xv;
+        int arg = lane < C ? lane : 0x7fffffff;
+        for (int off = 8; off > 0; off >>= 1) {        // lanes 0..15 hold the classes
+            const float om = __shfl_xor(mx, off, 64);
+            const int oa = __shfl_xor(arg, off, 64);
+            if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
         }
-        a.pair_row[p] = a.sel_row[base + sidx];
+        const float ex = lane < C ? expf(xv - mx) : 0.f;
+        float se = ex;
+        for (int off = 8; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
+        const float lse = mx + logf(se);
+        if (lane < C && a.train) dpool[lane] = expf(xv - lse) - (lane == y ? 1.f : 0.f);
+        if (lane == 0) {
+            a.loss[b] = lse - pooled_s[y];
+            a.pred[b] = arg;
+        }
+    }
+    MOC_STAMP(14);
+    if (!a.train) return;
+    __syncthreads();
+    MOC_STAMP(15);
+    // ---- pairs p = (class c, r-th pooled row): dz and the gathered H1 rows, one round of loads.
+    // Entries p >= P (a slide with fewer than K selected rows) are zero / repeat pair 0's row so the
+    // W1 kernel can run over the static bound C*K without reading n_pair.
+    const int P = C * k, Pmax = C * K;
+    // two (pair, hidden) elements per thread per sweep, both gathers in flight together
+    for (int e0 = threadIdx.x; e0 < Pmax * H; e0 += 2048) {
+        float hv[2];
+        int sx[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int e = e0 + t * 1024;
+            const int p = e >> 6, h = e & 63;
+            const int pp = p < P ? p : 0;
+            sx[t] = (P > 0 && e < Pmax * H) ? topk_s[(pp / k) * K + (pp - (pp / k) * k)] : 0;
+            hv[t] = (p < P && e < Pmax * H) ? a.H1[(base + sx[t]) * H + h] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int e = e0 + t * 1024;
+            if (e >= Pmax * H) continue;
+            const int p = e >> 6, h = e & 63, sidx = sx[t];
+            H1s[e] = hv[t];
+            if (h < 4) {
+                const int i = h;
+                float dzv = 0.f;
+                if (p < P) {
+                    const int c = p / k;
+                    const float g = dpool[c] / (float)k;
+                    const float* cd = a.cand + base + sidx;
+                    const float sc = i == 0 ? cd[(int64_t)c * a.stride] : i == 1 ? cd[(int64_t)(C + c) * a.stride]
+                                   : i == 2 ? cd[(int64_t)(2 * C) * a.stride] : cd[(int64_t)(2 * C + 1) * a.stride];
+                    const float lam = a.gates[(base + sidx) * 4 + i];
+                    const float dlam = (a.use_bits >> i & 1u) ? g * sc : 0.f;
+                    dzv = dlam * lam * (1.f - lam);
+                }
+                dz[p * 4 + i] = dzv;
+            }
+            if (h == 4) a.pair_row[p] = P > 0 ? a.sel_row[base + sidx] : 0;
+        }
     }
     if (threadIdx.x == 0) *a.n_pair = P;
     __syncthreads();
-    for (int e = threadIdx.x; e < P * H; e += 1024) H1s[e] = a.H1[(base + prow[e >> 6]) * H + (e & 63)];
-    __syncthreads();
+    MOC_STAMP(16);
     // dh[p][h] = (sum_i dz[p][i] * W2[i][h]) * [H1 > 0]
-    for (int e = threadIdx.x; e < P * H; e += 1024) {
+    for (int e = threadIdx.x; e < Pmax * H; e += 1024) {
         const int p = e >> 6, h = e & 63;
         float v = 0.f;
 #pragma unroll
@@ -505,26 +640,34 @@ __global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* po
         a.pair_dh[e] = v;
     }
     __syncthreads();
+    MOC_STAMP(17);
     const float gs = a.adam.grad_scale;
     if (threadIdx.x < 4 * H) {          // W2 [4][H]
         const int i = threadIdx.x >> 6, h = threadIdx.x & 63;
         float g = 0.f;
         for (int p = 0; p < P; ++p) g = fmaf(dz[p * 4 + i], H1s[p * H + h], g);
-        if (a.apply_adam) adam_update(a.W2[threadIdx.x], a.m_W2[threadIdx.x], a.v_W2[threadIdx.x], g * gs, a.adam);
-        else a.g_W2[threadIdx.x] = g;
+        if (a.apply_adam) {
+            adam_update(pW, pM, pV, g * gs, a.adam);
+            a.W2[threadIdx.x] = pW; a.m_W2[threadIdx.x] = pM; a.v_W2[threadIdx.x] = pV;
+        } else a.g_W2[threadIdx.x] = g;
     } else if (threadIdx.x < 4 * H + 4) {
         const int i = threadIdx.x - 4 * H;
         float g = 0.f;
         for (int p = 0; p < P; ++p) g += dz[p * 4 + i];
-        if (a.apply_adam) adam_update(a.b2[i], a.m_b2[i], a.v_b2[i], g * gs, a.adam);
-        else a.g_b2[i] = g;
+        if (a.apply_adam) {
+            adam_update(pW, pM, pV, g * gs, a.adam);
+            a.b2[i] = pW; a.m_b2[i] = pM; a.v_b2[i] = pV;
+        } else a.g_b2[i] = g;
     } else if (threadIdx.x >= 320 && threadIdx.x < 320 + H) {
         const int h = threadIdx.x - 320;
         float g = 0.f;
         for (int p = 0; p < P; ++p) g += dhs[p * H + h];
-        if (a.apply_adam) adam_update(a.b1[h], a.m_b1[h], a.v_b1[h], g * gs, a.adam);
-        else a.g_b1[h] = g;
+        if (a.apply_adam) {
+            adam_update(pW, pM, pV, g * gs, a.adam);
+            a.b1[h] = pW; a.m_b1[h] = pM; a.v_b1[h] = pV;
+        } else a.g_b1[h] = g;
     }
+    MOC_STAMP(18);
 }
 
 // ------------------------------------------------------------------ W1 gradient (+ Adam)
@@ -534,33 +677,52 @@ struct W1Args {
     const int64_t* pair_row;
     const int32_t* n_pair;
     float *W1, *m_W1, *v_W1, *g_W1;
+    unsigned char* W1img;   // kept in sync with W1 when the step is applied (nullable)
+    const float* pair_x;    // [P][D] fp32 rows gathered by the fused step (nullable: gather here)
     int D, apply_adam;
+    int P_static;           // >= 0: pair count known to the host (padded list), else read n_pair
     AdamCoef adam;
 };
 
 // dW1[h][d] = sum_p dh[p][h] * x_p[d] over the <= K*C gradient pairs, then Adam in place.
-// grid (D/256, H/8): a workgroup owns 256 columns d and 8 hidden units; the pairs' row segments
-// (P x 256 elements) and dh columns are staged in LDS with every load issued at once -- one
-// memory round trip instead of P dependent ones.
+// grid (D/256, H/8): a workgroup owns 256 columns d and 8 hidden units.  Everything it needs is
+// requested at once: its 8 x 256 parameters and moments, and the pairs' row segments (P x 256
+// elements, via LDS) -- with `P_static` >= 0 (the fused step pads its pair list to C*K entries with
+// zero dh) not even n_pair has to arrive first.
 constexpr int W1_MAXP = 64;
 template <bool BF16>
 __global__ __launch_bounds__(256) void w1_update_kernel(W1Args a) {
     __shared__ float xs[W1_MAXP][256];
     __shared__ float dh_s[W1_MAXP][8];
     const int d = blockIdx.x * 256 + threadIdx.x, h0 = blockIdx.y * 8;
-    const int P = *a.n_pair;
+    MOC_STAMP(20);
+    float pw[8], pm[8], pv[8];
+    if (a.apply_adam) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = (h0 + j) * a.D + d;
+            pw[j] = a.W1[e]; pm[j] = a.m_W1[e]; pv[j] = a.v_W1[e];
+        }
+    }
+    const int P = a.P_static >= 0 ? a.P_static : *a.n_pair;
     float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int p0 = 0; p0 < P; p0 += W1_MAXP) {
         const int np = P - p0 < W1_MAXP ? P - p0 : W1_MAXP;
         if (p0 > 0) __syncthreads();
+        if (a.pair_x) {
 #pragma unroll 8
-        for (int p = 0; p < np; ++p) {
-            const int64_t row = a.pair_row[p0 + p];
-            if constexpr (BF16) xs[p][threadIdx.x] = moc_bf16_to_f32(reinterpret_cast<const uint16_t*>(a.X)[row * a.D + d]);
-            else xs[p][threadIdx.x] = reinterpret_cast<const float*>(a.X)[row * a.D + d];
+            for (int p = 0; p < np; ++p) xs[p][threadIdx.x] = a.pair_x[(int64_t)(p0 + p) * a.D + d];
+        } else {
+#pragma unroll 8
+            for (int p = 0; p < np; ++p) {
+                const int64_t row = a.pair_row[p0 + p];
+                if constexpr (BF16) xs[p][threadIdx.x] = moc_bf16_to_f32(reinterpret_cast<const uint16_t*>(a.X)[row * a.D + d]);
+                else xs[p][threadIdx.x] = reinterpret_cast<const float*>(a.X)[row * a.D + d];
+            }
         }
         for (int e = threadIdx.x; e < np * 8; e += 256) dh_s[e >> 3][e & 7] = a.pair_dh[(p0 + (e >> 3)) * H + h0 + (e & 7)];
         __syncthreads();
+        MOC_STAMP(21);
         for (int p = 0; p < np; ++p) {
             const float xv = xs[p][threadIdx.x];
 #pragma unroll
@@ -570,9 +732,16 @@ __global__ __launch_bounds__(256) void w1_update_kernel(W1Args a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int e = (h0 + j) * a.D + d;
-        if (a.apply_adam) adam_update(a.W1[e], a.m_W1[e], a.v_W1[e], g[j] * a.adam.grad_scale, a.adam);
-        else a.g_W1[e] = g[j];
+        if (a.apply_adam) {
+            adam_update(pw[j], pm[j], pv[j], g[j] * a.adam.grad_scale, a.adam);
+            a.W1[e] = pw[j]; a.m_W1[e] = pm[j]; a.v_W1[e] = pv[j];
+            if (a.W1img) {
+                if constexpr (BF16) w1_image_store_bf16(a.W1img, a.D, h0 + j, d, pw[j]);
+                else w1_image_store_f32(a.W1img, a.D, h0 + j, d, pw[j]);
+            }
+        } else a.g_W1[e] = g[j];
     }
+    MOC_STAMP(22);
 }
 
 // gradients already in g_* (e.g. after an all-reduce): plain Adam over all four tensors
@@ -622,6 +791,15 @@ int check_meta(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* w
     return MOC_OK;
 }
 
+int launch_w1_image(const moc_batch_t* B, const moc_meta_t* M, hipStream_t s) {
+    MOC_REQUIRE(M->W1_image, "meta: W1_image buffer is null (moc_w1_image_bytes)");
+    const int grid = H * B->D / 256;
+    if (B->dtype == MOC_BF16) w1_image_kernel<true><<<grid, 256, 0, s>>>(M->W1, B->D, (unsigned char*)M->W1_image);
+    else w1_image_kernel<false><<<grid, 256, 0, s>>>(M->W1, B->D, (unsigned char*)M->W1_image);
+    MOC_CHECK_LAUNCH("moc_w1_image");
+    return MOC_OK;
+}
+
 int s_bound(const moc_batch_t* B) {
     const int64_t by_sel = (int64_t)B->topj * (2 * B->C + 2);
     return (int)(by_sel < B->max_rows ? by_sel : B->max_rows);
@@ -632,8 +810,10 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
     FwdArgs a;
     a.X = (const unsigned char*)B->X; a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel;
     a.cand = B->cand; a.W1 = M->W1; a.b1 = M->b1; a.W2 = M->W2; a.b2 = M->b2;
+    a.W1img = (const unsigned char*)M->W1_image;
     a.H1 = ws->H1; a.gates = ws->gates; a.mixed = ws->mixed; a.stride = B->total_rows;
     a.D = B->D; a.C = B->C; a.slide0 = slide0; a.use_bits = use_bits;
+    a.base_host = (n == 1 && B->row_off_host) ? B->row_off_host[slide0] : -1;
     dim3 grid(moc_cdiv(s_bound(B), 16), n);
     if (B->dtype == MOC_BF16) meta_forward_kernel<true><<<grid, 256, 0, s>>>(a);
     else meta_forward_kernel<false><<<grid, 256, 0, s>>>(a);
@@ -687,21 +867,32 @@ int launch_pool_finish(const moc_batch_t* B, const moc_meta_t* M, const moc_meta
     a.pair_dh = ws->pair_dh; a.pair_row = ws->pair_row; a.n_pair = ws->n_pair;
     a.stride = B->total_rows; a.C = B->C; a.K = B->topk; a.slide0 = slide0; a.train = train;
     a.apply_adam = apply_adam; a.use_bits = use_bits; a.adam = k;
+    a.pair_x = ws->pair_x; a.X = (const unsigned char*)B->X; a.D = B->D; a.bf16 = B->dtype == MOC_BF16;
+    a.base_host = -1; a.seg_host = 0;
+    if (n == 1 && B->row_off_host) {
+        a.base_host = B->row_off_host[slide0];
+        a.seg_host = (int)(B->row_off_host[slide0 + 1] - a.base_host);
+    }
     const size_t C = B->C, K = B->topk, PK = train ? C * K : 0;
-    const size_t smem = C * PS_CAP * 8 + C * 16 * 8 + C * 4 * 3 + C * K * 4 + PK * (4 * 4 + 4 + 2 * H * 4) + 4 * H * 4;
+    const int cap = C <= 8 ? PS_CAP_MAX : PS_CAP_MAX / 2;
+    const size_t smem = C * cap * 8 + C * 16 * 8 + C * 4 * 3 + C * K * 4 + PK * (4 * 4 + 2 * H * 4) + 4 * H * 4;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)pool_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    pool_step_kernel<<<n, 1024, smem, s>>>(a, ws->pooled, ws->topk_idx, ws->topk_cnt);
+    pool_step_kernel<<<n, 1024, smem, s>>>(a, ws->pooled, ws->topk_idx, ws->topk_cnt, cap);
     MOC_CHECK_LAUNCH("moc_pool_step");
     return MOC_OK;
 }
 
 int launch_w1(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, int apply_adam,
-              const AdamCoef& k, hipStream_t s) {
+              const AdamCoef& k, hipStream_t s, bool padded_pairs) {
     W1Args a;
+    a.P_static = padded_pairs ? B->C * B->topk : -1;
+    a.pair_x = nullptr;      // measured: gathering the pairs' rows in the single-workgroup step kernel
+                             // costs it more (+2 us) than this kernel saves (-1.4 us); gather here
+    a.W1img = (unsigned char*)M->W1_image;
     a.X = (const unsigned char*)B->X; a.pair_dh = ws->pair_dh; a.pair_row = ws->pair_row; a.n_pair = ws->n_pair;
     a.W1 = M->W1; a.m_W1 = M->m_W1; a.v_W1 = M->v_W1; a.g_W1 = M->g_W1; a.D = B->D; a.apply_adam = apply_adam; a.adam = k;
     const dim3 grid(B->D / 256, H / 8);
@@ -718,6 +909,8 @@ extern "C" int moc_meta_forward(const moc_batch_t* B, const moc_meta_t* M, const
     if (int rc = moc_check_batch(B, "moc_meta_forward")) return rc;
     if (int rc = check_meta(B, M, ws, "moc_meta_forward", false, false)) return rc;
     MOC_REQUIRE(slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_meta_forward: bad slide range");
+    // the parameters may have changed since the image was last written: rebuild it (H*D elements)
+    if (int rc = launch_w1_image(B, M, (hipStream_t)stream)) return rc;
     return launch_forward(B, M, ws, slide0, n, use_bits, (hipStream_t)stream);
 }
 
@@ -728,6 +921,7 @@ extern "C" int moc_mix_fixed(const moc_batch_t* B, const moc_meta_ws_t* ws, int 
     MOC_REQUIRE(slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_mix_fixed: bad slide range");
     MOC_REQUIRE(mode >= 0 && mode <= 2, "moc_mix_fixed: mode %d not in {0 avg, 1 sum, 2 max}", mode);
     FwdArgs a = {};
+    a.base_host = -1;
     a.row_off = B->row_off; a.n_sel = B->n_sel; a.cand = B->cand; a.mixed = ws->mixed;
     a.stride = B->total_rows; a.C = B->C; a.slide0 = slide0;
     fixed_mix_kernel<<<dim3(moc_cdiv(s_bound(B), 256), n), 256, 0, (hipStream_t)stream>>>(a, mode);
@@ -767,7 +961,7 @@ extern "C" int moc_train_grad(const moc_batch_t* B, const moc_meta_t* M, const m
     AdamCoef k = {};
     k.grad_scale = 1.f;
     if (int rc = launch_finish(B, M, ws, labels, slide, 1, 1, 0, use_bits, k, s)) return rc;
-    return launch_w1(B, M, ws, 0, k, s);
+    return launch_w1(B, M, ws, 0, k, s, false);
 }
 
 extern "C" int moc_adam_step(const moc_meta_t* M, float grad_scale, moc_stream_t stream) {
@@ -789,12 +983,18 @@ extern "C" int moc_train_steps(const moc_batch_t* B, const moc_meta_t* M, const 
     if (int rc = check_meta(B, M, ws, "moc_train_steps", true, false)) return rc;
     MOC_REQUIRE(labels && slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_train_steps: bad labels/slide range");
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = launch_w1_image(B, M, s)) return rc;      // afterwards the W1 update keeps it in sync
     for (int t = 0; t < n; ++t) {
         const int b = slide0 + t;
         const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f);
         if (int rc = launch_forward(B, M, ws, b, 1, use_bits, s)) return rc;
         if (int rc = launch_pool_finish(B, M, ws, labels, b, 1, 1, 1, use_bits, k, s)) return rc;
-        if (int rc = launch_w1(B, M, ws, 1, k, s)) return rc;
+        if (int rc = launch_w1(B, M, ws, 1, k, s, fused_ok(B, 1))) return rc;
     }
     return MOC_OK;
+}
+
+extern "C" size_t moc_w1_image_bytes(int D, int dtype) {
+    if (D <= 0) return 0;
+    return dtype == MOC_BF16 ? (size_t)D * H * 3 * 2 : (size_t)D * H * 4;
 }

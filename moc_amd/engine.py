@@ -89,6 +89,7 @@ class SlideBatch:
         for s in sizes:
             off.append(off[-1] + s)
         self.row_off_host = off
+        self._row_off_c = (C.c_int64 * len(off))(*off)        # host copy handed to the C ABI
         self.row_off = torch.tensor(off, dtype=torch.int64).to(dev, non_blocking=True)
         self.x_off = None
         if x_starts is not None:
@@ -112,7 +113,8 @@ class SlideBatch:
         self.cand = torch.empty((2 * self.C + 2, T), dtype=torch.float32, device=dev)
         self.c = MocBatch(
             X=ptr(X), dtype=_dtype_code(X.dtype), D=self.D, total_rows=T, n_slides=n, max_rows=max(sizes),
-            row_off=ptr(self.row_off), x_off=ptr(self.x_off), mask=ptr(self.mask), C=self.C, Ce=self.Ce, topj=self.topj,
+            row_off=ptr(self.row_off), row_off_host=C.cast(self._row_off_c, C.c_void_p), x_off=ptr(self.x_off),
+            mask=ptr(self.mask), C=self.C, Ce=self.Ce, topj=self.topj,
             topk=self.topk, discard_bits=self.discard_bits, reserved=0, kept=ptr(self.kept),
             n_kept=ptr(self.n_kept), stats=ptr(self.stats), sel_flag=ptr(self.sel_flag),
             sel_idx=ptr(self.sel_idx), sel_row=ptr(self.sel_row), n_sel=ptr(self.n_sel), cand=ptr(self.cand))
@@ -163,7 +165,7 @@ class SlideBatch:
                 mixed=torch.empty((Cc, T), **f32), pooled=torch.empty((n, Cc), **f32),
                 topk_idx=torch.empty((n, Cc, K), **i32), topk_cnt=torch.empty((n, Cc), **i32),
                 loss=torch.empty(n, **f32), pred=torch.empty(n, **i32),
-                pair_dh=torch.empty((Cc * K, HIDDEN), **f32),
+                pair_dh=torch.empty((Cc * K, HIDDEN), **f32), pair_x=torch.empty((Cc * K, self.D), **f32),
                 pair_row=torch.empty(Cc * K, dtype=torch.int64, device=dev), n_pair=torch.zeros(1, **i32))
             self._ws = (t, MocMetaWs(**{k: ptr(v) for k, v in t.items()}))
         return self._ws
@@ -175,7 +177,7 @@ class MetaState:
     `optimizer.state_dict()` / `model.state_dict()` stay what the reference saves
     (main_moc.py:628)."""
 
-    def __init__(self, model, optimizer=None, need_grads=False):
+    def __init__(self, model, optimizer=None, need_grads=False, bag_dtype=torch.bfloat16):
         lin1, lin2 = model.model[0], model.model[2]
         self.params = [lin1.weight, lin1.bias, lin2.weight, lin2.bias]
         assert lin1.out_features == HIDDEN and lin2.out_features == 4 and lin2.in_features == HIDDEN
@@ -210,6 +212,11 @@ class MetaState:
             self.grads = [torch.zeros_like(p) for p in self.params]
             for n, gt in zip(names, self.grads):
                 ptrs["g_" + n] = ptr(gt)
+        # scratch for the forward pass's operand-ordered copy of W1 (sized for the larger, bf16x3 form)
+        self.w1_image = torch.empty(max(lib().moc_w1_image_bytes(self.D, _lib.MOC_BF16),
+                                        lib().moc_w1_image_bytes(self.D, _lib.MOC_F32)),
+                                    dtype=torch.uint8, device=self.params[0].device)
+        ptrs["W1_image"] = ptr(self.w1_image)
         self.c = MocMeta(**ptrs, **kw)
 
     def advance(self, n_steps: int):

@@ -1,0 +1,45 @@
+"""Where a meta-step spends its microseconds: phase stamps from the diagnostic build
+(make -C moc_amd/csrc stamps; MOC_HIP_LIB=moc_amd/libmoc_hip_stamps.so).  Shares, not totals."""
+import os, sys, ctypes as C
+os.environ.setdefault("MOC_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "moc_amd", "libmoc_hip_stamps.so"))
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+torch.set_num_threads(8)
+from moc_amd import engine, main_moc as M, synth
+from moc_amd._lib import lib
+dev = torch.device("cuda:0")
+Cc, D, j, K = 2, 512, 400, 10
+W, We = synth.make_bank(1234, D, Cc)
+M.set_classifier_bank(W.to(dev), We.to(dev))
+bags = [synth.make_bag_device(1234 + i, 15000, D, We, Cc, i % Cc, dev, torch.bfloat16) for i in range(32)]
+res = M.ResidentBags(bags, [i % Cc for i in range(32)], dev)
+torch.manual_seed(0)
+model = M.senet(D, 4).to(dev); opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+bank = M._bank_for(res.X, dev)
+plan = res.train_plan(Cc, Cc + 4, j, K, [])
+batch, lab = plan["batch"], plan["labels"]
+m, kept = engine.draw_row_masks(batch.total); batch.set_mask(m, kept); batch.phase_a(bank)
+meta = engine.MetaState(model, opt)
+h = lib(); h.moc_debug_stamps.restype = C.c_int; h.moc_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+names = {0: "fwd begin", 1: "fwd mfma done", 2: "fwd end", 10: "pool begin", 11: "pool wave-max done", 12: "pool candidates done",
+         13: "pool extraction done", 14: "pool CE done", 15: "pool W2 staged", 16: "pool pairs done", 17: "pool dh done", 18: "pool end",
+         20: "w1 begin", 21: "w1 staged", 22: "w1 end"}
+acc = {}
+for rep in range(20):
+    engine.train_steps(batch, meta, lab, 0, 32, 15)     # stamps hold the LAST step (slide 31) of the call
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 128)()
+    assert h.moc_debug_stamps(buf, 128) == 0
+    t = {k: buf[k] for k in names}
+    cyc = {k: buf[64 + k] for k in names}
+    for a_, b_ in ((0, 2), (10, 18), (20, 22)):
+        acc.setdefault(("MHz", a_), []).append((cyc[b_] - cyc[a_]) / max(1, (t[b_] - t[a_])) * 100.0)
+    order = sorted(names, key=lambda k: t[k])
+    for a_, b_ in zip(order, order[1:]):
+        acc.setdefault((a_, b_), []).append((t[b_] - t[a_]) / 100.0)   # 100 MHz -> us
+for (a_, b_), v in acc.items():
+    v.sort()
+    if a_ == "MHz":
+        print(f"shader clock inside kernel starting at '{names[b_]}': median {v[len(v)//2]:7.0f} MHz")
+    else:
+        print(f"{names[a_]:24s} -> {names[b_]:24s} median {v[len(v)//2]:6.2f} us")
