@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-dp", action="store_true", help="run the data-parallel trainer even at 1 GPU (rehearsal)")
     return ap.parse_args()
 
 
@@ -79,9 +80,11 @@ def main():
     cpus = granted_cpus()
     torch.set_num_threads(max(1, min(8, cpus // max(1, world))))   # the GPU leg's host side is serial
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or a.force_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from moc_amd import engine, main_moc as M, synth
     from moc_amd import dist as mdist
@@ -110,7 +113,7 @@ def main():
         while done < n_steps:
             m = min(a.slides, n_steps - done)
             res.repeat_num = m if m < a.slides else None
-            if world == 1:
+            if world == 1 and not a.force_dp:
                 M.train(model, res, opt, dev, args)
             else:
                 mdist.train_dp(model, res, opt, dev, args)
@@ -228,7 +231,7 @@ def main():
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or a.force_dp:
         dist.destroy_process_group()
 
 

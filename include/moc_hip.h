@@ -196,8 +196,9 @@ int moc_pool_loss(const moc_batch_t* B, const moc_meta_ws_t* ws, const int64_t* 
 int moc_ce_loss(const float* pooled, const int64_t* labels, int n, int C, float* loss, int32_t* pred,
                 moc_stream_t stream);
 
-/* a14: gradients of slide `slide`'s loss w.r.t. the four parameter tensors, written
- * (not accumulated) to M->g_*.  Requires moc_meta_forward + moc_pool_loss of that slide. */
+/* a10-a14 for ONE slide without the update: forward, pooling, loss (ws->loss/pooled/pred) and
+ * the gradients of that loss w.r.t. the four parameter tensors, written (not accumulated) to
+ * M->g_*.  The data-parallel step all-reduces them and calls moc_adam_step. */
 int moc_train_grad(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
                    const int64_t* labels, int slide, uint32_t use_bits, moc_stream_t stream);
 

@@ -960,8 +960,12 @@ extern "C" int moc_train_grad(const moc_batch_t* B, const moc_meta_t* M, const m
     hipStream_t s = (hipStream_t)stream;
     AdamCoef k = {};
     k.grad_scale = 1.f;
-    if (int rc = launch_finish(B, M, ws, labels, slide, 1, 1, 0, use_bits, k, s)) return rc;
-    return launch_w1(B, M, ws, 0, k, s, false);
+    // forward (fresh W1 image: the parameters may have been stepped by moc_adam_step), pooling +
+    // loss + pair gradients, W1 gradient -- everything one meta-step does short of the update
+    if (int rc = launch_w1_image(B, M, s)) return rc;
+    if (int rc = launch_forward(B, M, ws, slide, 1, use_bits, s)) return rc;
+    if (int rc = launch_pool_finish(B, M, ws, labels, slide, 1, 1, 0, use_bits, k, s)) return rc;
+    return launch_w1(B, M, ws, 0, k, s, fused_ok(B, 1));
 }
 
 extern "C" int moc_adam_step(const moc_meta_t* M, float grad_scale, moc_stream_t stream) {

@@ -52,9 +52,10 @@ class FlatGrads:
 def allreduce_mean_(flat: torch.Tensor, group=None) -> float:
     """Sum-all-reduce in place; returns the scale (1/world) the caller applies
     (fused into the Adam kernel's grad_scale on the GPU path)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if not dist.is_initialized():
+        return 1.0
+    world = dist.get_world_size(group)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)      # also at world 1: same call path as N > 1
     return 1.0 / world
 
 
@@ -90,22 +91,26 @@ def train_dp(model, loader, optimizer, device, args, group=None):
     t-th slide of every rank.  All ranks must hold the same number of visits."""
     from . import engine, main_moc as M
     model.train()
-    X, sizes, x_starts, labels = M._collect(loader, device, args)
-    mask_all, _ = engine.draw_row_masks(sum(sizes))
-    masks, o = [], 0
-    for n in sizes:
-        masks.append(mask_all[o:o + n])
-        o += n
-    bank = M._bank_for(X, device)
+    use = engine.train_use_bits(args.discard_classifiers)
+    if isinstance(loader, M.ResidentBags):
+        batch, lab, bank = M._resident_pass_setup(loader, device, args)
+        sizes = batch.sizes
+    else:
+        X, sizes, x_starts, labels = M._collect(loader, device, args)
+        mask_all, _ = engine.draw_row_masks(sum(sizes))
+        masks, o = [], 0
+        for n in sizes:
+            masks.append(mask_all[o:o + n])
+            o += n
+        bank = M._bank_for(X, device)
+        batch = M._sub_batch(X, sizes, x_starts, list(range(len(sizes))), bank.C, bank.Ce, args.topj, args.topk,
+                             args.discard_classifiers, masks)
+        lab = torch.tensor(labels, dtype=torch.int64).to(device, non_blocking=True)
     meta = engine.MetaState(model, optimizer, need_grads=True)
     fg = FlatGrads(meta.params, device)
-    # point the C ABI's gradient outputs at the flat buffer
+    # point the C ABI's gradient outputs at the flat buffer: the all-reduce is ONE collective
     for name, v in zip(("g_W1", "g_b1", "g_W2", "g_b2"), fg.views):
         setattr(meta.c, name, v.data_ptr())
-    use = engine.train_use_bits(args.discard_classifiers)
-    batch = M._sub_batch(X, sizes, x_starts, list(range(len(sizes))), bank.C, bank.Ce, args.topj, args.topk,
-                         args.discard_classifiers, masks)
-    lab = torch.tensor(labels, dtype=torch.int64).to(device, non_blocking=True)
     batch.phase_a(bank)
     for t in range(len(sizes)):
         engine.train_grad(batch, meta, lab, t, use)

@@ -291,11 +291,8 @@ def train_steps(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, slide0
 def train_grad(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, slide: int, use_bits: int):
     """Forward + loss + gradients of one slide into meta.grads (no update)."""
     _, ws = batch.meta_ws()
-    s = _stream()
-    check(lib().moc_meta_forward(C.byref(batch.c), C.byref(meta.c), C.byref(ws), slide, 1, use_bits, s), "moc_meta_forward")
-    check(lib().moc_pool_loss(C.byref(batch.c), C.byref(ws), ptr(labels), slide, 1, s), "moc_pool_loss")
-    check(lib().moc_train_grad(C.byref(batch.c), C.byref(meta.c), C.byref(ws), ptr(labels), slide, use_bits, s),
-          "moc_train_grad")
+    check(lib().moc_train_grad(C.byref(batch.c), C.byref(meta.c), C.byref(ws), ptr(labels), slide, use_bits,
+                               _stream()), "moc_train_grad")
 
 
 def adam_step(meta: MetaState, grad_scale: float = 1.0):

@@ -223,25 +223,30 @@ def slide_process(feat, zeroshot_weights, zeroshot_weights_ext,
     }
 
 
+def _resident_pass_setup(res, device, args):
+    """Train pass over a resident split: nothing is copied or allocated per epoch except the new
+    mask bytes.  Returns (batch with this epoch's masks uploaded, device labels, bank)."""
+    bank = _bank_for(res.X, device)
+    assert bank.C == args.n_classes
+    plan = res.train_plan(bank.C, bank.Ce, args.topj, args.topk, args.discard_classifiers)
+    batch, lab = plan["batch"], plan["labels"]
+    t = plan["turn"] = (plan["turn"] + 1) % len(plan["stage"])
+    if plan["events"][t] is not None:
+        plan["events"][t].synchronize()               # that staging buffer's last upload has finished
+    stage, kept = engine.draw_row_masks(batch.total, plan["stage"][t])   # main_moc.py:330, same stream of bits
+    batch.set_mask(stage, kept)
+    ev = torch.cuda.Event()
+    ev.record()
+    plan["events"][t] = ev
+    return batch, lab, bank
+
+
 def train(model, train_loader, optimizer, device, args):
     """main_moc.py:378-410: one Adam step per slide, in loader order."""
     model.train()
     use = engine.train_use_bits(args.discard_classifiers)
     if isinstance(train_loader, ResidentBags):
-        # resident split: nothing is copied or allocated per epoch except the new mask bytes
-        res = train_loader
-        bank = _bank_for(res.X, device)
-        assert bank.C == args.n_classes
-        plan = res.train_plan(bank.C, bank.Ce, args.topj, args.topk, args.discard_classifiers)
-        batch, lab = plan["batch"], plan["labels"]
-        t = plan["turn"] = (plan["turn"] + 1) % len(plan["stage"])
-        if plan["events"][t] is not None:
-            plan["events"][t].synchronize()           # that staging buffer's last upload has finished
-        stage, kept = engine.draw_row_masks(batch.total, plan["stage"][t])   # main_moc.py:330, same stream of bits
-        batch.set_mask(stage, kept)
-        ev = torch.cuda.Event()
-        ev.record()
-        plan["events"][t] = ev
+        batch, lab, bank = _resident_pass_setup(train_loader, device, args)
         meta = MetaState(model, optimizer)
         batch.phase_a(bank)
         engine.train_steps(batch, meta, lab, 0, batch.n_slides, use)
