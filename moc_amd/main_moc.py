@@ -136,6 +136,20 @@ class ResidentBags:
                                        "events": [None, None, None], "turn": 0}
         return plan
 
+    def eval_plan(self, C_, Ce, topj, topk, discard):
+        """Work arrays + labels for an un-masked pass over the current visit order, reused across calls."""
+        order = tuple(self.visit_order())
+        key = ("eval", order, C_, Ce, topj, topk, tuple(sorted(discard or ())))
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) > 8:
+                self._plans.clear()
+            sizes = [self.sizes[k] for k in order]
+            batch = SlideBatch(self.X, sizes, C_, Ce, topj, topk, discard, x_starts=[self.starts[k] for k in order])
+            lab = torch.tensor([self.labels[k] for k in order], dtype=torch.int64).to(self.X.device)
+            plan = self._plans[key] = {"batch": batch, "labels": lab, "label_list": [self.labels[k] for k in order]}
+        return plan
+
     def real_len(self):
         return len(self.sizes)
 
@@ -294,21 +308,34 @@ def _metrics(pooled_cpu, labels, losses, n_div, real_len, args):
     return {"loss": test_loss, "acc": correct / real_len, "auc": auc}
 
 
-def _eval_pass(loader, device, args, mode, model=None, pooling_func=None):
+def _eval_batches(loader, device, args, mode):
+    """(batch, device labels, label list) per chunk of an evaluation pass."""
+    discard = args.discard_classifiers if mode == "eval" else []
+    if isinstance(loader, ResidentBags) and loader.X.numel() * loader.X.element_size() <= MAX_BATCH_BYTES:
+        bank = _bank_for(loader.X, device, fg_from_ext=(mode == "zs_bottomk"))
+        plan = loader.eval_plan(bank.C, bank.Ce, args.topj, args.topk, discard)
+        return bank, [(plan["batch"], plan["labels"], plan["label_list"])]
     X, sizes, x_starts, labels = _collect(loader, device, args)
     bank = _bank_for(X, device, fg_from_ext=(mode == "zs_bottomk"))
-    C_, Ce = bank.C, bank.Ce
-    meta = MetaState(model) if model is not None else None
-    pooled, losses = [], []
+    out = []
     for ids in _chunks(sizes, X.size(1), X.element_size()):
-        discard = args.discard_classifiers if mode == "eval" else []
-        batch = _sub_batch(X, sizes, x_starts, ids, C_, Ce, args.topj, args.topk, discard)
-        lab = torch.tensor([labels[i] for i in ids], dtype=torch.int64).to(device, non_blocking=True)
-        n = len(ids)
+        batch = _sub_batch(X, sizes, x_starts, ids, bank.C, bank.Ce, args.topj, args.topk, discard)
+        lab_list = [labels[i] for i in ids]
+        out.append((batch, torch.tensor(lab_list, dtype=torch.int64).to(device, non_blocking=True), lab_list))
+    return bank, out
+
+
+def _eval_pass(loader, device, args, mode, model=None, pooling_func=None):
+    bank, batches = _eval_batches(loader, device, args, mode)
+    C_ = bank.C
+    meta = MetaState(model) if model is not None else None
+    outs, labels = [], []
+    for batch, lab, lab_list in batches:
+        n = batch.n_slides
         tensors, _ = batch.meta_ws()
         if mode.startswith("zs"):
             batch.scores(bank)
-            st, T = batch.stats, batch.total
+            st = batch.stats
             kind = mode[3:]
             if kind == "topj":
                 keys, vals, small, shared = st[:C_], st[:C_], False, False
@@ -328,9 +355,11 @@ def _eval_pass(loader, device, args, mode, model=None, pooling_func=None):
             else:
                 engine.mix_fixed(batch, 0, n, args.ablation_study)
             engine.pool_loss(batch, lab, 0, n)
-        pooled.append(tensors["pooled"].cpu())
-        losses.extend(tensors["loss"].cpu().tolist())
-    return torch.cat(pooled, 0), labels, losses
+        # one device->host transfer per chunk: [n, C] pooled logits | loss
+        outs.append(torch.cat([tensors["pooled"], tensors["loss"].unsqueeze(1)], 1).cpu())
+        labels.extend(lab_list)
+    allv = torch.cat(outs, 0)
+    return allv[:, :-1].contiguous(), labels, allv[:, -1].tolist()
 
 
 def zs_evaluation(loader, device, args, pooling_func=topj_pooling):
