@@ -1,0 +1,247 @@
+"""Driver for the MOC path: the command line, data/weight
+preparation, `main()` and `--summary` of the reference's main_moc.py (:29-127, :161-293, :586-644)
+around the GPU callables of moc_amd.main_moc.
+
+    python -m moc_amd.run_moc --fold 0 --shot 16 --topj 400 --topk 10 --dataset nsclc
+    python -m moc_amd.run_moc --summary --summary_dir results/moc_train/nsclc
+    python -m moc_amd.run_moc --synthetic 24 --shot 4 --disable_tqdm        # no data needed
+
+Same flags and defaults as the reference, same result files (`zs_results_*`, `best_results_*`,
+`ablation_results_*`, `best_model_*.pt`, `summary_*.csv`) with the same keys.  Differences, all
+additive: the dataset branch is table driven (ebrains12 / ebrains30 work like nsclc / rcc); the
+CONCH text tower is not part of this path, so the zero-shot weights must already be cached under
+`models/classifier_weights/` (the reference caches them there on first run, main_moc.py:149-197);
+`--bag_dtype bf16` stores bags as bfloat16; `--resident 0` falls back to per-epoch re-reads;
+`--synthetic N` runs the whole loop on N generated slides per split.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+from glob import glob
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import main_moc as M
+from .datasets import Generic_MIL_Dataset, to_resident
+
+# dataset -> (csv, split dir, label map, weight file stems)   main_moc.py:161-293
+TASKS = {
+    "nsclc": dict(csv="dataset_csv/nsclc.csv", splits="splits/nsclc_fewshot", data="data/nsclc",
+                  labels={"LUAD": 0, "LUSC": 1}, weights="weights_nsclc_conch.pt", weights_ext="weights_nsclc_ext_conch.pt"),
+    "rcc": dict(csv="dataset_csv/rcc.csv", splits="splits/rcc_fewshot", data="data/rcc",
+                labels={"KICH": 0, "KIRC": 1, "KIRP": 2}, weights="weights_rcc_conch.pt", weights_ext="weights_rcc_ext_conch.pt"),
+    "ebrains12": dict(csv="dataset_csv/ebrains12.csv", splits="splits/ebrains12_fewshot", data="data/ebrains12",
+                      labels=None, weights="weights_ebrains12_conch.pt", weights_ext="weights_ebrains12_ext_conch.pt"),
+    "ebrains30": dict(csv="dataset_csv/ebrains30.csv", splits="splits/ebrains30_fewshot", data="data/ebrains30",
+                      labels=None, weights="weights_ebrains30_conch.pt", weights_ext="weights_ebrains30_ext_conch.pt"),
+}
+
+
+def get_args(argv=None):
+    p = argparse.ArgumentParser(description="Configurations for WSI Training")
+    p.add_argument("--fold", type=int, default=0, help="fold number")
+    p.add_argument("--shot", type=int, default=1, help="split number")
+    p.add_argument("--topj", type=int, default=10, help="topj for classifier selection")
+    p.add_argument("--topk", type=int, default=10, help="topk for final pooling")
+    p.add_argument("--result_dir", type=str, default="results/moc_train", help="result directory")
+    p.add_argument("--dataset", type=str, default="nsclc", choices=sorted(TASKS), help="dataset name")
+    p.add_argument("--pretrain", type=str, default="conch", choices=["conch"], help="pretrain model")
+    p.add_argument("--disable_tqdm", action="store_true", help="disable tqdm for better log")
+    p.add_argument("--discard_classifiers", nargs="+", default=[], help="topk, delta_softmax, delta_diff, bottomk")
+    p.add_argument("--load_weight", type=bool, default=True, help="load stored classifier weight")
+    p.add_argument("--check_zeroshot", type=bool, default=True, help="get zero-shot results")
+    p.add_argument("--ablation_study", type=str, default="none", choices=["none", "avg", "sum", "max"], help="ablation study")
+    p.add_argument("--summary", action="store_true", help="summary results, no training")
+    p.add_argument("--summary_dir", type=str, default="")
+    # additive
+    p.add_argument("--root", type=str, default=".", help="directory holding dataset_csv/, splits/, data/, models/")
+    p.add_argument("--bag_dtype", type=str, default="fp32", choices=["fp32", "bf16"], help="bag storage in HBM")
+    p.add_argument("--resident", type=int, default=1, help="keep each split packed in HBM across epochs")
+    p.add_argument("--epochs", type=int, default=25, help="main_moc.py:611 hard-codes 25")
+    p.add_argument("--synthetic", type=int, default=0, help="run on N generated slides per split instead of files")
+    p.add_argument("--seed", type=int, default=None, help="torch.manual_seed before building the meta-learner")
+    return p.parse_args(argv)
+
+
+# ------------------------------------------------------------------ --summary (main_moc.py:53-127)
+def _fold_results(summary_dir, shot, pattern="best_results_shot_{shot}_fold_{fold}.json"):
+    out = []
+    for fold in range(5):
+        with open(os.path.join(summary_dir, pattern.format(shot=shot, fold=fold))) as f:
+            out.append(json.load(f))
+    return out
+
+
+def summary(args):
+    print("start summary")
+    for shot in [1, 2, 4, 8]:
+        summary_dir = args.summary_dir + f"/{shot}_shot"
+        summary_file = os.path.join(args.summary_dir, f"summary_{shot}.csv")
+        folds = [0, 1, 2, 3, 4, "mean"]
+
+        def fresh():
+            if os.path.exists(summary_file):
+                os.remove(summary_file)
+
+        def col(vals):
+            return list(vals) + [np.mean(vals)]
+        try:
+            fresh()
+            r = _fold_results(summary_dir, shot)
+            pd.DataFrame({"fold": folds, "test_auc": col([x["test_at_best_val"] for x in r]),
+                          "zs_test_auc": col([x["zero_shot_test"]["auc"] for x in r]),
+                          "test_acc": col([x["test_acc_at_best_val"] for x in r]),
+                          "zs_test_acc": col([x["zero_shot_test"]["acc"] for x in r])}).to_csv(summary_file, index=False)
+        except Exception:
+            try:      # probably no zero-shot results
+                fresh()
+                r = _fold_results(summary_dir, shot)
+                pd.DataFrame({"fold": folds, "test_auc": col([x["test_at_best_val"] for x in r]),
+                              "test_acc": col([x["test_acc_at_best_val"] for x in r])}).to_csv(summary_file, index=False)
+            except Exception:
+                try:  # probably an ablation study
+                    fresh()
+                    r = []
+                    for fold in range(5):
+                        with open(glob(os.path.join(summary_dir, f"*_shot_{shot}_fold_{fold}.json"))[0]) as f:
+                            r.append(json.load(f))
+                    pd.DataFrame({"fold": folds, "auc": col([x["auc"] for x in r]),
+                                  "acc": col([x["acc"] for x in r])}).to_csv(summary_file, index=False)
+                except Exception:
+                    print(f"shot {shot} summary failed")
+    print("end summary")
+
+
+# ------------------------------------------------------------------ data / weights
+def _load_weights(args, task, device):
+    wdir = os.path.join(args.root, "models", "classifier_weights")
+    paths = [os.path.join(wdir, task["weights"]), os.path.join(wdir, task["weights_ext"])]
+    for pth in paths:
+        if not os.path.exists(pth):
+            raise FileNotFoundError(
+                f"{pth} is missing.  The zero-shot classifier weights come from the CONCH text tower "
+                "(utils/zeroshot_utils.py:20-51), which is outside this path; run the reference once "
+                "(it caches them there, main_moc.py:149-197) or copy the two .pt files.")
+    W, We = (torch.load(pth, map_location="cpu").to(torch.float32) for pth in paths)
+    print("zershot weights shape: ", W.shape)
+    print("zershot weights_ext shape: ", We.shape)
+    return W.to(device), We.to(device)
+
+
+def prepare(args, device):
+    """-> (train_loader, val_loader, test_loader) and the classifier bank installed in moc_amd.main_moc."""
+    if args.synthetic:
+        from . import synth
+        C = 2 if args.dataset == "nsclc" else 3 if args.dataset == "rcc" else 12 if args.dataset == "ebrains12" else 30
+        args.n_classes = C
+        W, We = synth.make_bank(1234, 512, C)
+        M.set_classifier_bank(W.to(device), We.to(device))
+        dt = torch.bfloat16 if args.bag_dtype == "bf16" else torch.float32
+        loaders = []
+        for s, (base, n, rep) in enumerate(((100, args.shot * C, args.shot * C), (5000, args.synthetic, None), (9000, args.synthetic, None))):
+            bags, labels = synth.make_slide_set(base, synth.bag_sizes(base, n, 3000, fixed=False, lo=500, hi=8000), 512, We, C)
+            loaders.append(M.ResidentBags(bags, labels, device, dtype=dt, repeat_num=rep))
+        return loaders
+    task = TASKS[args.dataset]
+    labels = task["labels"]
+    csv_path = os.path.join(args.root, task["csv"])
+    if labels is None:       # table driven: classes in order of first appearance in the slide table
+        seen = list(dict.fromkeys(pd.read_csv(csv_path, dtype=str)["label"]))
+        labels = {name: i for i, name in enumerate(seen)}
+    args.n_classes = len(labels)
+    W, We = _load_weights(args, task, device)
+    assert W.size(1) == args.n_classes and We.size(1) > W.size(1), "classifier bank does not match the label map"
+    M.set_classifier_bank(W, We)
+    data_dir = os.path.join(args.root, task["data"], "merge_features_conch")
+    dataset = Generic_MIL_Dataset(csv_path=csv_path, data_dir=data_dir, shuffle=False, seed=1, print_info=True,
+                                  label_dict=labels, patient_strat=False, ignore=[])
+    dataset.load_from_h5(True)
+    dataset.load_full_path(True)
+    splits = dataset.return_splits(from_id=False,
+                                   csv_path=os.path.join(args.root, task["splits"], f"{args.shot}shots", f"splits_{args.fold}.csv"),
+                                   repeat_num=int(args.shot) * args.n_classes)
+    loaders = []
+    for sp in splits:
+        sp.load_full_path(True)
+        sp.load_from_h5(True)
+        if args.resident:
+            loaders.append(to_resident(sp, device, torch.bfloat16 if args.bag_dtype == "bf16" else None))
+        else:
+            loaders.append(torch.utils.data.DataLoader(sp, batch_size=1, shuffle=False, num_workers=1))
+    return loaders
+
+
+# ------------------------------------------------------------------ main (main_moc.py:586-644)
+def main(args, model, optimizer, train_loader, val_loader, test_loader, device):
+    os.makedirs(args.result_dir, exist_ok=True)
+    if args.ablation_study != "none":
+        ablation_eval_dict = M.ablation_evaluation(test_loader, device, args)
+        print(f"Ablation Study: {args.ablation_study}, Test: {ablation_eval_dict}")
+        with open(os.path.join(args.result_dir, f"ablation_results_{args.ablation_study}_shot_{args.shot}_fold_{args.fold}.json"), "w") as f:
+            json.dump(ablation_eval_dict, f, indent=4)
+        return ablation_eval_dict
+
+    zs_train, zs_val, zs_test = -1, -1, -1
+    if args.check_zeroshot:
+        zs_train = M.zs_evaluation(train_loader, device, args)
+        zs_val = M.zs_evaluation(val_loader, device, args)
+        zs_test = M.zs_evaluation(test_loader, device, args)
+        print(f"Zero-shot Train: {zs_train}, Val: {zs_val}, Test: {zs_test}")
+        with open(os.path.join(args.result_dir, f"zs_results_shot_{args.shot}_fold_{args.fold}.json"), "w") as f:
+            json.dump({"zs_train": zs_train, "zs_val": zs_val, "zs_test": zs_test}, f, indent=4)
+
+    best_val = 0
+    test_at_best_val = 0
+    test_acc_at_best_val = 0
+    best_epoch = 0
+    model_path = os.path.join(args.result_dir, f"best_model_shot_{args.shot}_fold_{args.fold}.pt")
+    for epoch in range(getattr(args, "epochs", 25)):
+        print("Epoch: ", epoch)
+        M.train(model, train_loader, optimizer, device, args)
+        train_eval = M.evaluation(model, train_loader, device, args)
+        val_eval = M.evaluation(model, val_loader, device, args)
+        if val_eval["auc"] > best_val:          # the test split is only visited on improvement (:618-628)
+            test_eval = M.evaluation(model, test_loader, device, args)
+            print(f"Epoch: {epoch}, Train: {train_eval}, Val: {val_eval}, Test: {test_eval}")
+            best_val = val_eval["auc"]
+            test_at_best_val = test_eval["auc"]
+            test_acc_at_best_val = test_eval["acc"]
+            best_epoch = epoch
+            torch.save(model.state_dict(), model_path)
+        else:
+            print(f"Epoch: {epoch}, Train: {train_eval}, Val: {val_eval}")
+    print(f"Zero-shot Train: {zs_train}, Val: {zs_val}, Test: {zs_test}")
+    print(f"Best Val: {best_val}, Test at Best Val: {test_at_best_val}, Test acc: {test_acc_at_best_val}, Best Epoch: {best_epoch}")
+    results = {
+        "zero_shot_train": zs_train, "zero_shot_val": zs_val, "zero_shot_test": zs_test,
+        "best_val": best_val, "test_at_best_val": test_at_best_val, "test_acc_at_best_val": test_acc_at_best_val,
+        "best_epoch": best_epoch, "best_model_path": model_path,
+    }
+    with open(os.path.join(args.result_dir, f"best_results_shot_{args.shot}_fold_{args.fold}.json"), "w") as f:
+        json.dump(results, f, indent=4)
+    print("\nEnd training.")
+    return results
+
+
+def cli(argv=None):
+    args = get_args(argv)
+    if args.summary:
+        summary(args)
+        return None
+    if not torch.cuda.is_available():
+        raise RuntimeError("moc_amd needs a GPU: there is no CPU fallback")
+    device = torch.device("cuda")
+    train_loader, val_loader, test_loader = prepare(args, device)
+    if args.seed is not None:
+        torch.manual_seed(args.seed)
+    model = M.senet(512, 4).to(device)                                                   # main_moc.py:315
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)         # main_moc.py:316
+    return main(args, model, optimizer, train_loader, val_loader, test_loader, device)
+
+
+if __name__ == "__main__":
+    cli()

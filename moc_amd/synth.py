@@ -34,15 +34,24 @@ def make_bank(seed: int, D: int, C: int, n_bg: int = 4):
 
 
 def make_bag(seed: int, N: int, D: int, W_ext: torch.Tensor, C: int, label: int,
-             scale: float = 1.0) -> torch.Tensor:
-    """One slide [N,D] fp32 on the host."""
+             scale: float = 1.0, confusion: float = 0.0, gain: float = PLANT_GAIN) -> torch.Tensor:
+    """One slide [N,D] fp32 on the host.  `confusion` > 0 gives that share of the planted rows
+    the direction of a random OTHER class (a harder task: AUC < 1); 0 leaves the stream of random
+    numbers exactly as it was, so fixtures made without it do not change."""
     r = _rng(seed)
     x = r.standard_normal((N, D)).astype(np.float32)
     x /= np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-12)
     u = r.random(N)
     bank = W_ext.numpy()
     fg = u < PLANT_FRACTION
-    x[fg] += PLANT_GAIN * bank[:, label][None, :]
+    if confusion > 0.0:
+        r2 = _rng(seed + 7919)
+        wrong = fg & (r2.random(N) < confusion)
+        other = (label + 1 + r2.integers(0, C - 1, size=N)) % C
+        x[fg & ~wrong] += gain * bank[:, label][None, :]
+        x[wrong] += gain * bank[:, other[wrong]].T
+    else:
+        x[fg] += gain * bank[:, label][None, :]
     bg = (u >= PLANT_FRACTION) & (u < PLANT_FRACTION + BACKGROUND_FRACTION)
     which = r.integers(C, bank.shape[1], size=N)
     x[bg] += PLANT_GAIN * bank[:, which[bg]].T
@@ -61,10 +70,12 @@ def bag_sizes(seed: int, n_slides: int, mean_n: int, fixed: bool = True,
     return [int(v) for v in np.clip(n, lo, hi)]
 
 
-def make_slide_set(base_seed: int, sizes, D: int, W_ext: torch.Tensor, C: int):
+def make_slide_set(base_seed: int, sizes, D: int, W_ext: torch.Tensor, C: int, confusion: float = 0.0,
+                   gain: float = PLANT_GAIN):
     """Host bags + round-robin labels (every class present when len>=C)."""
     labels = [i % C for i in range(len(sizes))]
-    bags = [make_bag(base_seed + i, n, D, W_ext, C, labels[i]) for i, n in enumerate(sizes)]
+    bags = [make_bag(base_seed + i, n, D, W_ext, C, labels[i], confusion=confusion, gain=gain)
+            for i, n in enumerate(sizes)]
     return bags, labels
 
 

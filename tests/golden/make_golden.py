@@ -47,13 +47,14 @@ from utils.patch_selection_classifier import (  # noqa: E402  (reference)
 
 torch.set_num_threads(1)   # fixed reduction order inside aten on this host
 
-WANTED = {"senet", "slide_process", "train", "zs_evaluation", "evaluation", "ablation_evaluation"}
+WANTED = {"senet", "slide_process", "train", "zs_evaluation", "evaluation", "ablation_evaluation", "main"}
 
 
 def load_reference_main():
     tree = ast.parse(open(os.path.join(REF, "main_moc.py")).read())
     body = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in WANTED]
-    ns = dict(torch=torch, nn=nn, F=F, np=np, tqdm=tqdm, roc_auc_score=roc_auc_score,
+    import json
+    ns = dict(torch=torch, nn=nn, F=F, np=np, tqdm=tqdm, roc_auc_score=roc_auc_score, os=os, json=json,
               index_topj_classifier=index_topj_classifier,
               index_delta_diff_classifier=index_delta_diff_classifier,
               index_delta_softmax_classifier=index_delta_softmax_classifier,
@@ -299,10 +300,109 @@ def gen_eval(ref):
     save("evaluation", **out)
 
 
+def gen_driver(ref):
+    """(6) the reference's main(): zero-shot evals, 25 epochs, best-val bookkeeping, result JSON."""
+    import json
+    import tempfile
+    out, cases = {}, []
+    cfgs = [(8, 12, 16, 2, 100, 10, 8), (6, 12, 15, 3, 60, 10, 9)]   # n_train, n_val, n_test, C, topj, topk, repeat_num
+    for cid, (ntr, nva, nte, C, j, K, rep) in enumerate(cfgs):
+        seed = 12000 + cid
+        W, We = synth.make_bank(seed, 512, C)
+        sets = []
+        for s_i, n in enumerate((ntr, nva, nte)):
+            sizes = synth.bag_sizes(seed + 10 * s_i, n, 400, fixed=False, lo=150, hi=900)
+            sets.append(synth.make_slide_set(seed + 1000 * (s_i + 1), sizes, 512, We, C, confusion=0.47, gain=0.12))
+        ref["zeroshot_weights"], ref["zeroshot_weights_ext"] = W, We
+        ref["train_loader"] = FakeLoader(*sets[0], rep)
+        ref["val_loader"] = FakeLoader(*sets[1])
+        ref["test_loader"] = FakeLoader(*sets[2])
+        ref["device"] = "cpu"
+        torch.manual_seed(seed)
+        ref["model"] = ref["senet"](512, 4)
+        ref["optimizer"] = torch.optim.Adam(ref["model"].parameters(), lr=1e-3, weight_decay=1e-4)
+        val_aucs, orig_eval = [], ref["evaluation"]
+
+        def logged(model, loader, device, args, _o=orig_eval):
+            r = _o(model, loader, device, args)
+            if loader is ref["val_loader"]:
+                val_aucs.append(r["auc"])
+            return r
+        ref["evaluation"] = logged
+        with tempfile.TemporaryDirectory() as td:
+            a = _args(C, j, K)
+            a.result_dir, a.shot, a.fold, a.check_zeroshot = td, 4, 0, True
+            torch.manual_seed(seed + 1)
+            ref["main"](a)
+            res = json.load(open(os.path.join(td, "best_results_shot_4_fold_0.json")))
+            zs = json.load(open(os.path.join(td, "zs_results_shot_4_fold_0.json")))
+            best_state = torch.load(res["best_model_path"])
+        ref["evaluation"] = orig_eval
+        out[f"c{cid}_result"] = np.array([res["best_val"], res["test_at_best_val"], res["test_acc_at_best_val"], res["best_epoch"]])
+        out[f"c{cid}_zs"] = np.array([[zs[k]["loss"], zs[k]["acc"], zs[k]["auc"]] for k in ("zs_train", "zs_val", "zs_test")])
+        out[f"c{cid}_val_auc"] = np.array(val_aucs)
+        out[f"c{cid}_best_params"] = torch.cat([v.reshape(-1) for v in best_state.values()]).numpy()
+        out[f"c{cid}_final_params"] = flat_params(ref["model"])
+        for s_i, (bags, _) in enumerate(sets):
+            out[f"c{cid}_sizes{s_i}"] = np.array([b.size(0) for b in bags])
+        cases.append((cid, ntr, nva, nte, C, j, K, rep, seed))
+    out["cases"] = np.array(cases, dtype=np.int64)
+    save("driver", **out)
+
+
+def summary_inputs(td, kind):
+    """Deterministic fake result files for --summary: kind in {full, nozs, ablation}."""
+    import json
+    rs = np.random.RandomState(5)
+    for shot in (1, 2, 4, 8):
+        d = os.path.join(td, f"{shot}_shot")
+        os.makedirs(d, exist_ok=True)
+        for fold in range(5):
+            v = rs.rand(6).round(6).tolist()
+            if kind == "ablation":
+                obj, name = {"loss": v[0], "acc": v[1], "auc": v[2]}, f"ablation_results_avg_shot_{shot}_fold_{fold}.json"
+            else:
+                obj = {"zero_shot_train": -1, "zero_shot_val": -1,
+                       "zero_shot_test": {"loss": v[0], "acc": v[1], "auc": v[2]} if kind == "full" else -1,
+                       "best_val": v[3], "test_at_best_val": v[4], "test_acc_at_best_val": v[5], "best_epoch": fold}
+                name = f"best_results_shot_{shot}_fold_{fold}.json"
+            json.dump(obj, open(os.path.join(d, name), "w"))
+
+
+def gen_summary():
+    """(7) --summary: the reference's top-level `if args.summary:` block (main_moc.py:53-127), run on fake results."""
+    import glob as _glob
+    import json
+    import tempfile
+    import pandas as pd
+    tree = ast.parse(open(os.path.join(REF, "main_moc.py")).read())
+    node = [n for n in tree.body if isinstance(n, ast.If) and "summary" in ast.unparse(n.test)][0]
+    body = [n for n in node.body if not (isinstance(n, ast.Expr) and "exit" in ast.unparse(n))]
+    code = compile(ast.Module(body=body, type_ignores=[]), "main_moc.py:summary", "exec")
+    out = {}
+    for kind in ("full", "nozs", "ablation"):
+        with tempfile.TemporaryDirectory() as td:
+            summary_inputs(td, kind)
+            exec(code, dict(args=types.SimpleNamespace(summary_dir=td), os=os, json=json, np=np, pd=pd, glob=_glob.glob))
+            for shot in (1, 2, 4, 8):
+                df = pd.read_csv(os.path.join(td, f"summary_{shot}.csv"))
+                out[f"{kind}_{shot}_cols"] = np.array(list(df.columns))
+                out[f"{kind}_{shot}_vals"] = df.drop(columns=["fold"]).to_numpy(dtype=np.float64)
+    save("summary", **out)
+
+
 if __name__ == "__main__":
+    only = sys.argv[1:]          # e.g. `make_golden.py driver` regenerates one fixture
     ref = load_reference_main()
+    if only:
+        for name in only:
+            fn = globals()["gen_" + name]
+            fn(ref) if fn.__code__.co_argcount else fn()
+        sys.exit(0)
     gen_selectors()
     gen_slide_process(ref)
     gen_pooling()
     gen_train(ref)
     gen_eval(ref)
+    gen_driver(ref)
+    gen_summary()
