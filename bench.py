@@ -232,6 +232,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         print(json.dumps(out))
     if world > 1 or a.force_dp:
+        mdist.shutdown()
         dist.destroy_process_group()
 
 

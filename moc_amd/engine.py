@@ -295,9 +295,10 @@ def train_grad(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, slide: 
                                _stream()), "moc_train_grad")
 
 
-def adam_step(meta: MetaState, grad_scale: float = 1.0):
+def adam_step(meta: MetaState, grad_scale: float = 1.0, advance: bool = True):
     check(lib().moc_adam_step(C.byref(meta.c), C.c_float(grad_scale), _stream()), "moc_adam_step")
-    meta.advance(1)
+    if advance:
+        meta.advance(1)
 
 
 def topk_mean(keys: torch.Tensor, vals: torch.Tensor, K: int, smallest=False, key_shared=False,
