@@ -457,3 +457,42 @@ def test_full_size_properties(dev):
     np.testing.assert_allclose(pooled_all.cpu().numpy(), ref_pooled.numpy(), atol=ATOL)
     ev = M.evaluation(model, H.ListLoader(cpu_bags, labels), dev, args)
     assert abs(ev["loss"] - ev_ref["loss"]) < ATOL and ev["acc"] == ev_ref["acc"] and abs(ev["auc"] - ev_ref["auc"]) < 2e-3
+
+
+# ------------------------------------------------------------------ paths the fixtures do not reach
+@pytest.mark.parametrize("C,K,j,D,dtype,sizes", [
+    (2, 20, 100, 512, torch.float32, [900, 700, 1100]),        # K > 16: general pooling + step kernels
+    (2, 1, 50, 512, torch.bfloat16, [600, 800]),               # K = 1
+    (3, 10, 5000, 512, torch.float32, [300, 420, 380]),        # topj > N': every kept row selected
+    (2, 10, 60, 768, torch.bfloat16, [500, 650]),              # 1536-byte rows: the 512-B-unit kernels
+    (2, 10, 400, 512, torch.float32, [12, 30, 9]),             # S < K on some slides (mean over S rows)
+    (5, 13, 40, 256, torch.float32, [400, 300, 350, 500, 450]),
+])
+def test_train_and_eval_match_oracle_on_odd_shapes(dev, C, K, j, D, dtype, sizes):
+    M = _mm()
+    W, We = synth.make_bank(900 + C * K, D, C)
+    bags, labels = synth.make_slide_set(9100 + K, sizes, D, We, C)
+    bags = [b.to(dtype) for b in bags]
+    ref_bags = [b.to(torch.float32) for b in bags]
+    torch.manual_seed(4)
+    ref_model = O.Senet(D, 4)
+    ref_opt = O.make_optimizer(ref_model)
+    torch.manual_seed(4)
+    model = M.senet(D, 4).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    M.set_classifier_bank(W.to(dev), We.to(dev))
+    args = H.make_args(C, j, K)
+    res = M.ResidentBags(bags, labels, dev)
+    for epoch in range(2):
+        torch.manual_seed(300 + epoch)
+        ref_losses = O.train_epoch(ref_model, ref_opt, ref_bags, labels, W, We, C, j, K)
+        torch.manual_seed(300 + epoch)
+        M.train(model, res, opt, dev, args)
+        got = M.train.last[0].meta_ws()[0]["loss"].cpu().numpy()
+        np.testing.assert_allclose(got, np.asarray(ref_losses), atol=ATOL)
+    H.assert_adam_params_close(H.flat_params(model), H.flat_params(ref_model), H.flat_state(ref_opt, "exp_avg_sq"),
+                               step=2 * len(sizes), grad_noise=1e-6, what=f"C={C} K={K} D={D}")
+    if len(set(labels)) == C:
+        ev_ref = O.evaluation(ref_model, ref_bags, labels, W, We, C, j, K)
+        ev = M.evaluation(model, res, dev, args)
+        assert abs(ev["loss"] - ev_ref["loss"]) < ATOL and ev["acc"] == ev_ref["acc"] and abs(ev["auc"] - ev_ref["auc"]) < 2e-3
