@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
 // They go to a short LDS list per class, and one wave per class extracts them in value order
 // (K wave-wide max reductions over the short list, DPP row operations, no LDS round trips).
 constexpr int PS_VPT = 4;       // values per thread per class  (S <= 4096)
+constexpr int FS_MAX_XS = 20480; // one-launch step: pair rows staged in LDS, C*K*D <= this many floats (80 KiB)
 constexpr int PS_CAP_MAX = 1024; // candidate list entries per class (the launch picks cap <= this)
 
 // inclusive max-scan by DPP row shifts, then the wave total from lane 63 (gfx9 DPP controls:
@@ -405,32 +406,26 @@ __device__ __forceinline__ unsigned long long ps_key(const float* col, int i, in
     return i < S ? ((unsigned long long)moc_key_desc(col[i]) << 32) | (unsigned)(~(unsigned)i) : 0ull;
 }
 
-// grid (n): one workgroup (1024 threads) per slide
-__global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* pooled_out, int32_t* topk_idx_out,
-                                                         int32_t* topk_cnt_out, int PS_CAP) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = a.slide0 + blockIdx.x, C = a.C, K = a.K;
+struct PoolLds {
+    unsigned long long *list, *wmax;     // [C][cap] candidate keys, [C][16] per-wave maxima
+    float *pooled_s, *dpool;             // [C] pooled logits, d loss / d pooled
+    int *ncand, *topk_s;                 // [C] candidate counts, [C][K] pooled rows in value order
+};
+
+// Pooling + loss of slide b by ONE workgroup of 16 waves (all threads must call): leaves the pooled
+// rows in L.topk_s, the pooled logits in L.pooled_s and (train) d loss/d pooled in L.dpool; returns
+// k = rows pooled per class.  `write_out`: this workgroup also publishes pooled/topk/loss/pred.
+__device__ __forceinline__ int pool_phase(const FinishArgs& a, int b, const PoolLds& L, int PS_CAP, bool write_out,
+                                          float* pooled_out, int32_t* topk_idx_out, int32_t* topk_cnt_out,
+                                          int64_t* base_out) {
+    const int C = a.C, K = a.K;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // LDS carve (all dynamic)
-    unsigned long long* list = reinterpret_cast<unsigned long long*>(smem);          // [C][PS_CAP]
-    unsigned long long* wmax = list + (size_t)C * PS_CAP;                           // [C][16]
-    float* pooled_s = reinterpret_cast<float*>(wmax + (size_t)C * 16);               // [C]
-    float* dpool = pooled_s + C;                                                     // [C]
-    int* ncand = reinterpret_cast<int*>(dpool + C);                                  // [C]
-    int* topk_s = ncand + C;                                                         // [C][K]
-    float* dz = reinterpret_cast<float*>(topk_s + C * K);                            // [P][4]   (train)
-    float* H1s = dz + (size_t)C * K * 4;                                             // [P][H]
-    float* dhs = H1s + (size_t)C * K * H;                                            // [P][H]
-    float* W2s = dhs + (size_t)C * K * H;                                            // [4][H]
-    MOC_STAMP(10);
-    // operands that do not depend on this slide's scores: requested first, consumed last
-    float pW = 0.f, pM = 0.f, pV = 0.f;       // parameter / exp_avg / exp_avg_sq this thread will step
-    if (a.train) {
-        const int t = threadIdx.x;
-        if (t < 4 * H) { W2s[t] = pW = a.W2[t]; if (a.apply_adam) { pM = a.m_W2[t]; pV = a.v_W2[t]; } }
-        else if (t < 4 * H + 4) { pW = a.b2[t - 4 * H]; if (a.apply_adam) { pM = a.m_b2[t - 4 * H]; pV = a.v_b2[t - 4 * H]; } }
-        else if (t >= 320 && t < 320 + H) { pW = a.b1[t - 320]; if (a.apply_adam) { pM = a.m_b1[t - 320]; pV = a.v_b1[t - 320]; } }
-    }
+    unsigned long long* list = L.list;
+    unsigned long long* wmax = L.wmax;
+    float* pooled_s = L.pooled_s;
+    float* dpool = L.dpool;
+    int* ncand = L.ncand;
+    int* topk_s = L.topk_s;
     const int64_t base = a.base_host >= 0 ? a.base_host : a.row_off[b];
     const int seg = a.base_host >= 0 ? a.seg_host : (int)(a.row_off[b + 1] - base);   // reads below stay inside the slide's slots
     const int y = (int)a.labels[b];
@@ -552,11 +547,11 @@ __global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* po
             pooled_s[c] = __uint_as_float(0x7FC00000u);     // mean over no rows = NaN, like torch
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
+        if (lane == 0 && write_out) {
             pooled_out[(int64_t)b * C + c] = pooled_s[c];
             if (topk_cnt_out) topk_cnt_out[(int64_t)b * C + c] = k;
         }
-        if (topk_idx_out)
+        if (topk_idx_out && write_out)
             for (int r = lane; r < K; r += 64)
                 topk_idx_out[((int64_t)b * C + c) * K + r] = r < k ? topk_s[c * K + r] : -1;
     }
@@ -577,11 +572,43 @@ __global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* po
         for (int off = 8; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
         const float lse = mx + logf(se);
         if (lane < C && a.train) dpool[lane] = expf(xv - lse) - (lane == y ? 1.f : 0.f);
-        if (lane == 0) {
+        if (lane == 0 && write_out) {
             a.loss[b] = lse - pooled_s[y];
             a.pred[b] = arg;
         }
     }
+    *base_out = base;
+    return k;
+}
+
+// grid (n): one workgroup (1024 threads) per slide
+__global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* pooled_out, int32_t* topk_idx_out,
+                                                         int32_t* topk_cnt_out, int PS_CAP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = a.slide0 + blockIdx.x, C = a.C, K = a.K;
+    // LDS carve (all dynamic)
+    unsigned long long* list = reinterpret_cast<unsigned long long*>(smem);          // [C][PS_CAP]
+    unsigned long long* wmax = list + (size_t)C * PS_CAP;                           // [C][16]
+    float* pooled_s = reinterpret_cast<float*>(wmax + (size_t)C * 16);               // [C]
+    float* dpool = pooled_s + C;                                                     // [C]
+    int* ncand = reinterpret_cast<int*>(dpool + C);                                  // [C]
+    int* topk_s = ncand + C;                                                         // [C][K]
+    float* dz = reinterpret_cast<float*>(topk_s + C * K);                            // [P][4]   (train)
+    float* H1s = dz + (size_t)C * K * 4;                                             // [P][H]
+    float* dhs = H1s + (size_t)C * K * H;                                            // [P][H]
+    float* W2s = dhs + (size_t)C * K * H;                                            // [4][H]
+    MOC_STAMP(10);
+    // operands that do not depend on this slide's scores: requested first, consumed last
+    float pW = 0.f, pM = 0.f, pV = 0.f;       // parameter / exp_avg / exp_avg_sq this thread will step
+    if (a.train) {
+        const int t = threadIdx.x;
+        if (t < 4 * H) { W2s[t] = pW = a.W2[t]; if (a.apply_adam) { pM = a.m_W2[t]; pV = a.v_W2[t]; } }
+        else if (t < 4 * H + 4) { pW = a.b2[t - 4 * H]; if (a.apply_adam) { pM = a.m_b2[t - 4 * H]; pV = a.v_b2[t - 4 * H]; } }
+        else if (t >= 320 && t < 320 + H) { pW = a.b1[t - 320]; if (a.apply_adam) { pM = a.m_b1[t - 320]; pV = a.v_b1[t - 320]; } }
+    }
+    int64_t base;
+    const PoolLds L = {list, wmax, pooled_s, dpool, ncand, topk_s};
+    const int k = pool_phase(a, b, L, PS_CAP, true, pooled_out, topk_idx_out, topk_cnt_out, &base);
     MOC_STAMP(14);
     if (!a.train) return;
     __syncthreads();
@@ -666,6 +693,171 @@ __global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* po
             adam_update(pW, pM, pV, g * gs, a.adam);
             a.b1[h] = pW; a.m_b1[h] = pM; a.v_b1[h] = pV;
         } else a.g_b1[h] = g;
+    }
+    MOC_STAMP(18);
+}
+
+// ---- pooling + loss + backward + the WHOLE Adam step in one launch --------------------------------
+// grid (H/4): every workgroup repeats the (cheap, latency-bound) pooling of the slide for itself --
+// 16 workgroups doing it side by side cost no more time than one -- and then owns 4 hidden units of
+// W1 (4 x D parameters): it forms their gradient from the <= C*K pairs it has just found and steps
+// them.  No pair list goes through memory, no second launch, no dependent n_pair -> row -> load chain.
+// Workgroup 0 also publishes the slide's outputs and steps b1, W2, b2; since every workgroup READS
+// W2 (for dh) while workgroup 0 WRITES it, W2 is double buffered by the caller (W2 in, W2out out).
+struct FusedArgs {
+    FinishArgs f;
+    float *W1, *m_W1, *v_W1;
+    unsigned char* W1img;
+    float* W2out;
+    int img_bf16;
+};
+
+
+__global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* pooled_out, int32_t* topk_idx_out,
+                                                            int32_t* topk_cnt_out, int PS_CAP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FinishArgs& a = g.f;
+    const int b = a.slide0, C = a.C, K = a.K, D = a.D;
+    const int wg = blockIdx.x, h_lo = wg * 4;
+    unsigned long long* list = reinterpret_cast<unsigned long long*>(smem);          // [C][PS_CAP]
+    unsigned long long* wmax = list + (size_t)C * PS_CAP;                           // [C][16]
+    float* pooled_s = reinterpret_cast<float*>(wmax + (size_t)C * 16);               // [C]
+    float* dpool = pooled_s + C;                                                     // [C]
+    int* ncand = reinterpret_cast<int*>(dpool + C);                                  // [C]
+    int* topk_s = ncand + C;                                                         // [C][K]
+    float* dz = reinterpret_cast<float*>(topk_s + C * K);                            // [P][4]
+    float* H1s = dz + (size_t)C * K * 4;                                             // [P][H]
+    float* dhs = H1s + (size_t)C * K * H;                                            // [P][H]
+    float* W2s = dhs + (size_t)C * K * H;                                            // [4][H]
+    int* sidx_s = reinterpret_cast<int*>(W2s + 4 * H);                               // [P]
+    float* xs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(sidx_s + C * K) + 15) & ~(uintptr_t)15);   // [P][D], 16-B aligned
+    MOC_STAMP(10);
+    // operands that do not depend on this slide's scores: requested first, consumed last.
+    // thread t: column d = t % D' of hidden units h_lo + 2*(t / D') + {0, 1}, D' = min(D, 512)
+    const int t = threadIdx.x;
+    const int dcols = D < 512 ? D : 512;                 // columns covered per sweep by 1024 threads (2 h each)
+    const int hh = t / dcols, dl = t - hh * dcols;       // hh in {0, 1} when dcols == 512
+    const bool own = hh < 2;                             // D < 512: the threads beyond 2*D idle in the W1 part
+    float pw[2][2], pm[2][2], pv[2][2];                  // [h sub-index][d sweep]  (D <= 1024)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int sw = 0; sw < 2; ++sw) {
+            const int d = dl + sw * dcols;
+            if (own && d < D) {
+                const int e = (h_lo + hh * 2 + j) * D + d;
+                pw[j][sw] = g.W1[e]; pm[j][sw] = g.m_W1[e]; pv[j][sw] = g.v_W1[e];
+            }
+        }
+    float pW = 0.f, pM = 0.f, pV = 0.f;                  // workgroup 0: W2 / b2 / b1 element of this thread
+    if (t < 4 * H) W2s[t] = a.W2[t];
+    if (wg == 0) {
+        if (t < 4 * H) { pW = W2s[t]; pM = a.m_W2[t]; pV = a.v_W2[t]; }
+        else if (t < 4 * H + 4) { pW = a.b2[t - 4 * H]; pM = a.m_b2[t - 4 * H]; pV = a.v_b2[t - 4 * H]; }
+        else if (t >= 320 && t < 320 + H) { pW = a.b1[t - 320]; pM = a.m_b1[t - 320]; pV = a.v_b1[t - 320]; }
+    }
+    int64_t base;
+    const PoolLds L = {list, wmax, pooled_s, dpool, ncand, topk_s};
+    const int k = pool_phase(a, b, L, PS_CAP, wg == 0, pooled_out, topk_idx_out, topk_cnt_out, &base);
+    __syncthreads();
+    MOC_STAMP(15);
+    // ---- pairs: position of each pair's row, then one round of gathers (dz operands, H1, bag rows)
+    const int P = C * k;
+    for (int p = t; p < P; p += 1024) sidx_s[p] = topk_s[(p / k) * K + (p - (p / k) * k)];
+    __syncthreads();
+    for (int e = t; e < P * 4; e += 1024) {               // dz[p][i]
+        const int p = e >> 2, i = e & 3, c = p / k, sidx = sidx_s[p];
+        const float* cd = a.cand + base + sidx;
+        const float sc = i == 0 ? cd[(int64_t)c * a.stride] : i == 1 ? cd[(int64_t)(C + c) * a.stride]
+                       : i == 2 ? cd[(int64_t)(2 * C) * a.stride] : cd[(int64_t)(2 * C + 1) * a.stride];
+        const float lam = a.gates[(base + sidx) * 4 + i];
+        const float dlam = (a.use_bits >> i & 1u) ? (dpool[c] / (float)k) * sc : 0.f;
+        dz[e] = dlam * lam * (1.f - lam);
+    }
+    {   // H1 of the pairs: workgroup 0 needs all H columns (b1, W2), the others their 4
+        const int hn = wg == 0 ? H : 4, h0 = wg == 0 ? 0 : h_lo;
+        for (int e = t; e < P * hn; e += 1024) {
+            const int p = e / hn, h = h0 + (e - p * hn);
+            H1s[p * H + h] = a.H1[(base + sidx_s[p]) * H + h];
+        }
+    }
+    {   // bag rows of the pairs -> fp32 in LDS, whole rows, contiguous
+        const int vpr = D / 4;                             // 4-element groups per row
+        for (int e = t; e < P * vpr; e += 1024) {
+            const int p = e / vpr, v = e - p * vpr;
+            const int64_t row = a.sel_row[base + sidx_s[p]];
+            float4 o;
+            if (a.bf16) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(a.X + (row * D + v * 4) * 2);
+                o.x = __uint_as_float(raw.x << 16); o.y = __uint_as_float(raw.x & 0xFFFF0000u);
+                o.z = __uint_as_float(raw.y << 16); o.w = __uint_as_float(raw.y & 0xFFFF0000u);
+            } else {
+                o = *reinterpret_cast<const float4*>(a.X + (row * D + v * 4) * 4);
+            }
+            *reinterpret_cast<float4*>(xs + (size_t)p * D + v * 4) = o;
+        }
+    }
+    __syncthreads();
+    MOC_STAMP(16);
+    {   // dh[p][h] = (sum_i dz[p][i] * W2[i][h]) * [H1 > 0]  for this workgroup's columns
+        const int hn = wg == 0 ? H : 4, h0 = wg == 0 ? 0 : h_lo;
+        for (int e = t; e < P * hn; e += 1024) {
+            const int p = e / hn, h = h0 + (e - p * hn);
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v = fmaf(dz[p * 4 + i], W2s[i * H + h], v);
+            dhs[p * H + h] = H1s[p * H + h] > 0.f ? v : 0.f;
+        }
+    }
+    __syncthreads();
+    MOC_STAMP(17);
+    // ---- W1: gradient of the owned elements and their Adam step (parameter, moments, operand image)
+    if (own) {
+#pragma unroll
+        for (int sw = 0; sw < 2; ++sw) {
+            const int d = dl + sw * dcols;
+            if (d < D) {
+                float g0 = 0.f, g1 = 0.f;
+                const int ha = h_lo + hh * 2;
+                for (int p = 0; p < P; ++p) {
+                    const float xv = xs[(size_t)p * D + d];
+                    g0 = fmaf(dhs[p * H + ha], xv, g0);
+                    g1 = fmaf(dhs[p * H + ha + 1], xv, g1);
+                }
+                const float gr[2] = {g0, g1};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int e = (ha + j) * D + d;
+                    adam_update(pw[j][sw], pm[j][sw], pv[j][sw], gr[j] * a.adam.grad_scale, a.adam);
+                    g.W1[e] = pw[j][sw]; g.m_W1[e] = pm[j][sw]; g.v_W1[e] = pv[j][sw];
+                    if (g.img_bf16) w1_image_store_bf16(g.W1img, D, ha + j, d, pw[j][sw]);
+                    else w1_image_store_f32(g.W1img, D, ha + j, d, pw[j][sw]);
+                }
+            }
+        }
+    }
+    // ---- workgroup 0: b1, W2 (into the other buffer), b2
+    if (wg == 0) {
+        const float gs = a.adam.grad_scale;
+        if (t < 4 * H) {
+            const int i = t >> 6, h = t & 63;
+            float gsum = 0.f;
+            for (int p = 0; p < P; ++p) gsum = fmaf(dz[p * 4 + i], H1s[p * H + h], gsum);
+            adam_update(pW, pM, pV, gsum * gs, a.adam);
+            g.W2out[t] = pW; a.m_W2[t] = pM; a.v_W2[t] = pV;
+        } else if (t < 4 * H + 4) {
+            const int i = t - 4 * H;
+            float gsum = 0.f;
+            for (int p = 0; p < P; ++p) gsum += dz[p * 4 + i];
+            adam_update(pW, pM, pV, gsum * gs, a.adam);
+            a.b2[i] = pW; a.m_b2[i] = pM; a.v_b2[i] = pV;
+        } else if (t >= 320 && t < 320 + H) {
+            const int h = t - 320;
+            float gsum = 0.f;
+            for (int p = 0; p < P; ++p) gsum += dhs[p * H + h];
+            adam_update(pW, pM, pV, gsum * gs, a.adam);
+            a.b1[h] = pW; a.m_b1[h] = pM; a.v_b1[h] = pV;
+        }
     }
     MOC_STAMP(18);
 }
@@ -886,6 +1078,51 @@ int launch_pool_finish(const moc_batch_t* B, const moc_meta_t* M, const moc_meta
     return MOC_OK;
 }
 
+size_t fused_step_smem(const moc_batch_t* B, int cap) {
+    const size_t C = B->C, K = B->topk, PK = C * K;
+    return C * cap * 8 + C * 16 * 8 + C * 4 * 3 + C * K * 4 + PK * (4 * 4 + 2 * H * 4) + 4 * H * 4 + PK * 4 + 16 +
+           PK * (size_t)B->D * 4;
+}
+
+// the one-launch step (pool_w1_step_kernel) applies when the pairs' rows fit in LDS
+bool fused_step_ok(const moc_batch_t* B, const moc_meta_ws_t* ws) {
+    if (!fused_ok(B, 1) || !ws->W2_alt) return false;
+    if (B->D > 1024 || (int64_t)B->C * B->topk * B->D > FS_MAX_XS) return false;
+    const int cap = B->C <= 8 ? PS_CAP_MAX : PS_CAP_MAX / 2;
+    return fused_step_smem(B, cap) <= 160 * 1024;
+}
+
+int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels,
+                      int slide, uint32_t use_bits, const AdamCoef& k, float* W2out, hipStream_t s) {
+    FusedArgs g = {};
+    FinishArgs& a = g.f;
+    a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel; a.cand = B->cand;
+    a.H1 = ws->H1; a.gates = ws->gates; a.pooled = ws->pooled; a.mixed_in = ws->mixed;
+    a.labels = labels; a.loss = ws->loss; a.pred = ws->pred;
+    a.W2 = M->W2; a.b2 = M->b2; a.b1 = M->b1;
+    a.m_W2 = M->m_W2; a.m_b2 = M->m_b2; a.m_b1 = M->m_b1; a.v_W2 = M->v_W2; a.v_b2 = M->v_b2; a.v_b1 = M->v_b1;
+    a.stride = B->total_rows; a.C = B->C; a.K = B->topk; a.slide0 = slide; a.train = 1;
+    a.apply_adam = 1; a.use_bits = use_bits; a.adam = k;
+    a.X = (const unsigned char*)B->X; a.D = B->D; a.bf16 = B->dtype == MOC_BF16;
+    a.base_host = -1; a.seg_host = 0;
+    if (B->row_off_host) {
+        a.base_host = B->row_off_host[slide];
+        a.seg_host = (int)(B->row_off_host[slide + 1] - a.base_host);
+    }
+    g.W1 = M->W1; g.m_W1 = M->m_W1; g.v_W1 = M->v_W1; g.W1img = (unsigned char*)M->W1_image;
+    g.W2out = W2out; g.img_bf16 = B->dtype == MOC_BF16;
+    const int cap = B->C <= 8 ? PS_CAP_MAX : PS_CAP_MAX / 2;
+    const size_t smem = fused_step_smem(B, cap);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)pool_w1_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    pool_w1_step_kernel<<<H / 4, 1024, smem, s>>>(g, ws->pooled, ws->topk_idx, ws->topk_cnt, cap);
+    MOC_CHECK_LAUNCH("moc_fused_step");
+    return MOC_OK;
+}
+
 int launch_w1(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, int apply_adam,
               const AdamCoef& k, hipStream_t s, bool padded_pairs) {
     W1Args a;
@@ -988,6 +1225,26 @@ extern "C" int moc_train_steps(const moc_batch_t* B, const moc_meta_t* M, const 
     MOC_REQUIRE(labels && slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_train_steps: bad labels/slide range");
     hipStream_t s = (hipStream_t)stream;
     if (int rc = launch_w1_image(B, M, s)) return rc;      // afterwards the W1 update keeps it in sync
+    if (fused_step_ok(B, ws)) {
+        // two launches per meta-step: forward, then pooling + loss + backward + the whole Adam step.
+        // W2 is read by every workgroup of the second kernel while workgroup 0 steps it: ping-pong.
+        moc_meta_t Mt = *M;
+        float* cur = M->W2;
+        float* nxt = ws->W2_alt;
+        for (int t = 0; t < n; ++t) {
+            const int b = slide0 + t;
+            const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f);
+            Mt.W2 = cur;
+            if (int rc = launch_forward(B, &Mt, ws, b, 1, use_bits, s)) return rc;
+            if (int rc = launch_fused_step(B, &Mt, ws, labels, b, use_bits, k, nxt, s)) return rc;
+            float* tmp = cur; cur = nxt; nxt = tmp;
+        }
+        if (cur != M->W2) {   // odd number of steps: the current W2 lives in the scratch buffer
+            if (hipMemcpyAsync(M->W2, cur, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                MOC_FAIL(MOC_ELAUNCH, "moc_train_steps: copy-back of W2 failed");
+        }
+        return MOC_OK;
+    }
     for (int t = 0; t < n; ++t) {
         const int b = slide0 + t;
         const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f);

@@ -23,7 +23,7 @@ meta = engine.MetaState(model, opt)
 h = lib(); h.moc_debug_stamps.restype = C.c_int; h.moc_debug_stamps.argtypes = [C.c_void_p, C.c_int]
 names = {0: "fwd begin", 1: "fwd mfma done", 2: "fwd end", 10: "pool begin", 11: "pool wave-max done", 12: "pool candidates done",
          13: "pool extraction done", 14: "pool CE done", 15: "pool W2 staged", 16: "pool pairs done", 17: "pool dh done", 18: "pool end",
-         20: "w1 begin", 21: "w1 staged", 22: "w1 end"}
+         }   # (the W1 update is part of the pool kernel now: one-launch step)
 acc = {}
 for rep in range(20):
     engine.train_steps(batch, meta, lab, 0, 32, 15)     # stamps hold the LAST step (slide 31) of the call
@@ -32,7 +32,7 @@ for rep in range(20):
     assert h.moc_debug_stamps(buf, 128) == 0
     t = {k: buf[k] for k in names}
     cyc = {k: buf[64 + k] for k in names}
-    for a_, b_ in ((0, 2), (10, 18), (20, 22)):
+    for a_, b_ in ((0, 2), (10, 18)):
         acc.setdefault(("MHz", a_), []).append((cyc[b_] - cyc[a_]) / max(1, (t[b_] - t[a_])) * 100.0)
     order = sorted(names, key=lambda k: t[k])
     for a_, b_ in zip(order, order[1:]):
