@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 4
+#define MOC_ABI_VERSION 5
 
 enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
 
@@ -206,6 +206,20 @@ int moc_train_grad(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
 
 /* a15: one Adam step (coupled L2) from M->g_* scaled by grad_scale; uses step = M->step+1. */
 int moc_adam_step(const moc_meta_t* M, float grad_scale, moc_stream_t stream);
+
+/* e (data-parallel training): `n` synchronous steps on THIS rank's slides slide0..slide0+n-1.
+ * Per step: forward, pooling, loss and gradients (as moc_train_grad), ONE all-reduce of the
+ * flat gradient, the Adam step with grad_scale = 1/world (as moc_adam_step, step = M->step+1+t).
+ * The collective is the caller's: `allreduce` has ncclAllReduce's signature (RCCL is not linked
+ * into this library) and is called as allreduce(grad_flat, grad_flat, grad_count, ncclFloat32,
+ * ncclSum, comm, stream); M->g_* must point into grad_flat.  NULL allreduce with world == 1
+ * runs the same step sequence without a collective.  M->step itself is not advanced. */
+typedef int (*moc_allreduce_fn)(const void* sendbuf, void* recvbuf, size_t count, int datatype, int op,
+                                void* comm, moc_stream_t stream);
+int moc_train_steps_dp(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
+                       const int64_t* labels, int slide0, int n, uint32_t use_bits,
+                       float* grad_flat, int64_t grad_count, moc_allreduce_fn allreduce,
+                       void* comm, int world, moc_stream_t stream);
 
 /* a10-a15 fused: `n` consecutive meta-steps (one slide each, slides slide0..slide0+n-1 in
  * order, one Adam step per slide: main_moc.py:380-410), parameters and Adam moments

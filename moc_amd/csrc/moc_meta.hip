@@ -706,7 +706,7 @@ __global__ __launch_bounds__(1024) void pool_step_kernel(FinishArgs a, float* po
 // W2 (for dh) while workgroup 0 WRITES it, W2 is double buffered by the caller (W2 in, W2out out).
 struct FusedArgs {
     FinishArgs f;
-    float *W1, *m_W1, *v_W1;
+    float *W1, *m_W1, *v_W1, *g_W1;
     unsigned char* W1img;
     float* W2out;
     int img_bf16;
@@ -744,14 +744,15 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
 #pragma unroll
         for (int sw = 0; sw < 2; ++sw) {
             const int d = dl + sw * dcols;
-            if (own && d < D) {
+            pw[j][sw] = pm[j][sw] = pv[j][sw] = 0.f;
+            if (own && d < D && a.apply_adam) {
                 const int e = (h_lo + hh * 2 + j) * D + d;
                 pw[j][sw] = g.W1[e]; pm[j][sw] = g.m_W1[e]; pv[j][sw] = g.v_W1[e];
             }
         }
     float pW = 0.f, pM = 0.f, pV = 0.f;                  // workgroup 0: W2 / b2 / b1 element of this thread
     if (t < 4 * H) W2s[t] = a.W2[t];
-    if (wg == 0) {
+    if (wg == 0 && a.apply_adam) {
         if (t < 4 * H) { pW = W2s[t]; pM = a.m_W2[t]; pV = a.v_W2[t]; }
         else if (t < 4 * H + 4) { pW = a.b2[t - 4 * H]; pM = a.m_b2[t - 4 * H]; pV = a.v_b2[t - 4 * H]; }
         else if (t >= 320 && t < 320 + H) { pW = a.b1[t - 320]; pM = a.m_b1[t - 320]; pV = a.v_b1[t - 320]; }
@@ -828,6 +829,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int e = (ha + j) * D + d;
+                    if (!a.apply_adam) { g.g_W1[e] = gr[j]; continue; }       // gradient out (data-parallel step)
                     adam_update(pw[j][sw], pm[j][sw], pv[j][sw], gr[j] * a.adam.grad_scale, a.adam);
                     g.W1[e] = pw[j][sw]; g.m_W1[e] = pm[j][sw]; g.v_W1[e] = pv[j][sw];
                     if (g.img_bf16) w1_image_store_bf16(g.W1img, D, ha + j, d, pw[j][sw]);
@@ -843,20 +845,29 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
             const int i = t >> 6, h = t & 63;
             float gsum = 0.f;
             for (int p = 0; p < P; ++p) gsum = fmaf(dz[p * 4 + i], H1s[p * H + h], gsum);
-            adam_update(pW, pM, pV, gsum * gs, a.adam);
-            g.W2out[t] = pW; a.m_W2[t] = pM; a.v_W2[t] = pV;
+            if (!a.apply_adam) a.g_W2[t] = gsum;
+            else {
+                adam_update(pW, pM, pV, gsum * gs, a.adam);
+                g.W2out[t] = pW; a.m_W2[t] = pM; a.v_W2[t] = pV;
+            }
         } else if (t < 4 * H + 4) {
             const int i = t - 4 * H;
             float gsum = 0.f;
             for (int p = 0; p < P; ++p) gsum += dz[p * 4 + i];
-            adam_update(pW, pM, pV, gsum * gs, a.adam);
-            a.b2[i] = pW; a.m_b2[i] = pM; a.v_b2[i] = pV;
+            if (!a.apply_adam) a.g_b2[i] = gsum;
+            else {
+                adam_update(pW, pM, pV, gsum * gs, a.adam);
+                a.b2[i] = pW; a.m_b2[i] = pM; a.v_b2[i] = pV;
+            }
         } else if (t >= 320 && t < 320 + H) {
             const int h = t - 320;
             float gsum = 0.f;
             for (int p = 0; p < P; ++p) gsum += dhs[p * H + h];
-            adam_update(pW, pM, pV, gsum * gs, a.adam);
-            a.b1[h] = pW; a.m_b1[h] = pM; a.v_b1[h] = pV;
+            if (!a.apply_adam) a.g_b1[h] = gsum;
+            else {
+                adam_update(pW, pM, pV, gsum * gs, a.adam);
+                a.b1[h] = pW; a.m_b1[h] = pM; a.v_b1[h] = pV;
+            }
         }
     }
     MOC_STAMP(18);
@@ -937,7 +948,8 @@ __global__ __launch_bounds__(256) void w1_update_kernel(W1Args a) {
 }
 
 // gradients already in g_* (e.g. after an all-reduce): plain Adam over all four tensors
-__global__ __launch_bounds__(256) void adam_all_kernel(moc_meta_t M, int D, AdamCoef k) {
+// (+ the W1 image when `img` is given, so that the next forward needs no rebuild)
+__global__ __launch_bounds__(256) void adam_all_kernel(moc_meta_t M, int D, AdamCoef k, unsigned char* img, int img_bf16) {
     const int nW1 = H * D, n = nW1 + H + 4 * H + 4;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
@@ -948,6 +960,10 @@ __global__ __launch_bounds__(256) void adam_all_kernel(moc_meta_t M, int D, Adam
     else if ((o -= H) < 4 * H) { p = M.W2; m = M.m_W2; v = M.v_W2; g = M.g_W2; }
     else { o -= 4 * H; p = M.b2; m = M.m_b2; v = M.v_b2; g = M.g_b2; }
     adam_update(p[o], m[o], v[o], g[o] * k.grad_scale, k);
+    if (img && e < nW1) {
+        if (img_bf16) w1_image_store_bf16(img, D, e / D, e % D, p[o]);
+        else w1_image_store_f32(img, D, e / D, e % D, p[o]);
+    }
 }
 
 AdamCoef adam_coef(const moc_meta_t* M, int64_t step, float grad_scale) {
@@ -1093,7 +1109,8 @@ bool fused_step_ok(const moc_batch_t* B, const moc_meta_ws_t* ws) {
 }
 
 int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels,
-                      int slide, uint32_t use_bits, const AdamCoef& k, float* W2out, hipStream_t s) {
+                      int slide, uint32_t use_bits, const AdamCoef& k, float* W2out, hipStream_t s,
+                      int apply_adam = 1) {
     FusedArgs g = {};
     FinishArgs& a = g.f;
     a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel; a.cand = B->cand;
@@ -1102,7 +1119,8 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
     a.W2 = M->W2; a.b2 = M->b2; a.b1 = M->b1;
     a.m_W2 = M->m_W2; a.m_b2 = M->m_b2; a.m_b1 = M->m_b1; a.v_W2 = M->v_W2; a.v_b2 = M->v_b2; a.v_b1 = M->v_b1;
     a.stride = B->total_rows; a.C = B->C; a.K = B->topk; a.slide0 = slide; a.train = 1;
-    a.apply_adam = 1; a.use_bits = use_bits; a.adam = k;
+    a.apply_adam = apply_adam; a.use_bits = use_bits; a.adam = k;
+    a.g_W2 = M->g_W2; a.g_b2 = M->g_b2; a.g_b1 = M->g_b1; g.g_W1 = M->g_W1;
     a.X = (const unsigned char*)B->X; a.D = B->D; a.bf16 = B->dtype == MOC_BF16;
     a.base_host = -1; a.seg_host = 0;
     if (B->row_off_host) {
@@ -1201,6 +1219,7 @@ extern "C" int moc_train_grad(const moc_batch_t* B, const moc_meta_t* M, const m
     // loss + pair gradients, W1 gradient -- everything one meta-step does short of the update
     if (int rc = launch_w1_image(B, M, s)) return rc;
     if (int rc = launch_forward(B, M, ws, slide, 1, use_bits, s)) return rc;
+    if (fused_step_ok(B, ws)) return launch_fused_step(B, M, ws, labels, slide, use_bits, k, nullptr, s, 0);
     if (int rc = launch_pool_finish(B, M, ws, labels, slide, 1, 1, 0, use_bits, k, s)) return rc;
     return launch_w1(B, M, ws, 0, k, s, fused_ok(B, 1));
 }
@@ -1212,8 +1231,46 @@ extern "C" int moc_adam_step(const moc_meta_t* M, float grad_scale, moc_stream_t
                 "moc_adam_step: null tensor");
     const AdamCoef k = adam_coef(M, M->step + 1, grad_scale);
     const int n = H * M->D + H + 4 * H + 4;
-    adam_all_kernel<<<moc_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(*M, M->D, k);
+    adam_all_kernel<<<moc_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(*M, M->D, k, nullptr, 0);
     MOC_CHECK_LAUNCH("moc_adam_step");
+    return MOC_OK;
+}
+
+extern "C" int moc_train_steps_dp(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
+                                  const int64_t* labels, int slide0, int n, uint32_t use_bits,
+                                  float* grad_flat, int64_t grad_count, moc_allreduce_fn allreduce,
+                                  void* comm, int world, moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_train_steps_dp")) return rc;
+    if (int rc = check_meta(B, M, ws, "moc_train_steps_dp", true, true)) return rc;
+    MOC_REQUIRE(labels && slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_train_steps_dp: bad labels/slide range");
+    const int64_t n_par = (int64_t)H * M->D + H + 4 * H + 4;
+    MOC_REQUIRE(world >= 1 && (world == 1 || allreduce), "moc_train_steps_dp: world %d needs an all-reduce", world);
+    MOC_REQUIRE(!allreduce || (grad_flat && grad_count >= n_par && M->g_W1 >= grad_flat &&
+                               M->g_W1 + (int64_t)H * M->D <= grad_flat + grad_count),
+                "moc_train_steps_dp: the gradient tensors must live in grad_flat[%lld]", (long long)grad_count);
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = launch_w1_image(B, M, s)) return rc;      // afterwards the Adam kernel keeps it in sync
+    const bool fused = fused_step_ok(B, ws);
+    const int img_bf16 = B->dtype == MOC_BF16;
+    AdamCoef kg = {};
+    kg.grad_scale = 1.f;
+    for (int t = 0; t < n; ++t) {
+        const int b = slide0 + t;
+        if (int rc = launch_forward(B, M, ws, b, 1, use_bits, s)) return rc;
+        if (fused) {
+            if (int rc = launch_fused_step(B, M, ws, labels, b, use_bits, kg, nullptr, s, 0)) return rc;
+        } else {
+            if (int rc = launch_pool_finish(B, M, ws, labels, b, 1, 1, 0, use_bits, kg, s)) return rc;
+            if (int rc = launch_w1(B, M, ws, 0, kg, s, fused_ok(B, 1))) return rc;
+        }
+        if (allreduce) {   // the ONE collective of a step: sum of the flat gradient over the ranks
+            const int rc = allreduce(grad_flat, grad_flat, (size_t)grad_count, 7 /* ncclFloat32 */, 0 /* ncclSum */, comm, stream);
+            if (rc != 0) MOC_FAIL(MOC_ELAUNCH, "moc_train_steps_dp: all-reduce failed at step %d (rc=%d)", t, rc);
+        }
+        const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f / (float)world);
+        adam_all_kernel<<<moc_cdiv(n_par, 256), 256, 0, s>>>(*M, M->D, k, (unsigned char*)M->W1_image, img_bf16);
+        MOC_CHECK_LAUNCH("moc_train_steps_dp");
+    }
     return MOC_OK;
 }
 

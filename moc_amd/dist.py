@@ -125,6 +125,37 @@ def meta_grad_allreduce(flat: torch.Tensor, group=None):
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
 
 
+def allreduce_entry(flat: torch.Tensor, group=None):
+    """-> (function address, comm, keepalive) for moc_train_steps_dp: ncclAllReduce itself and this
+    module's communicator when direct RCCL came up; otherwise a ctypes callback with the same
+    signature that runs torch.distributed's all-reduce of `flat` (gloo, or nccl without the direct
+    path).  (None, None, None) outside a process group."""
+    import ctypes as C
+    if not dist.is_initialized():
+        return None, None, None
+    if flat.is_cuda and dist.get_backend(group) == "nccl":
+        key = (id(group), flat.device.index)
+        d = _direct.get(key)
+        if d is None:
+            d = _direct[key] = DirectRccl(flat.device, group)
+        if d.ok:
+            return C.cast(d.lib.ncclAllReduce, C.c_void_p), d.comm, d
+    proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+
+    def _cb(send, recv, count, dtype, op, comm, stream):
+        try:
+            assert send == recv == flat.data_ptr() and count == flat.numel()
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception:  # noqa: BLE001 -- reported to the C caller as a failed collective
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    fn = proto(_cb)
+    return C.cast(fn, C.c_void_p), None, fn
+
+
 def shutdown():
     for d in _direct.values():
         d.close()
@@ -195,13 +226,11 @@ def train_dp(model, loader, optimizer, device, args, group=None):
         setattr(meta.c, name, v.data_ptr())
     batch.phase_a(bank)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    scale = 1.0 / world
-    for t in range(len(sizes)):
-        engine.train_grad(batch, meta, lab, t, use)
-        meta_grad_allreduce(fg.flat, group)                               # the ONE collective of a step
-        engine.adam_step(meta, scale, advance=False)
-        meta.c.step += 1
-    meta.c.step -= len(sizes)
+    # the whole pass is ONE call: per step forward, pool+loss+gradients, the ONE collective (the
+    # flat gradient), Adam with 1/world -- the host loop lives in C (moc_train_steps_dp)
+    fn, comm, keep = allreduce_entry(fg.flat, group)
+    engine.train_steps_dp(batch, meta, lab, 0, len(sizes), use, fg.flat, fn, comm, world)
+    del keep
     meta.advance(len(sizes))            # the optimizer's own step counters, once per pass
     train_dp.last = (batch, lab, fg)
 

@@ -289,6 +289,16 @@ def train_steps(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, slide0
     meta.advance(n)
 
 
+def train_steps_dp(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, slide0: int, n: int, use_bits: int,
+                   grad_flat: torch.Tensor, allreduce_fn, comm, world: int):
+    """n synchronous data-parallel steps on this rank's slides; `allreduce_fn` is the address of a
+    function with ncclAllReduce's signature (None at world 1).  Does not advance the step counters."""
+    _, ws = batch.meta_ws()
+    check(lib().moc_train_steps_dp(C.byref(batch.c), C.byref(meta.c), C.byref(ws), ptr(labels), slide0, n,
+                                   use_bits, ptr(grad_flat), grad_flat.numel(), allreduce_fn, comm, world,
+                                   _stream()), "moc_train_steps_dp")
+
+
 def train_grad(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, slide: int, use_bits: int):
     """Forward + loss + gradients of one slide into meta.grads (no update)."""
     _, ws = batch.meta_ws()
