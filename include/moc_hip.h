@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 5
+#define MOC_ABI_VERSION 6
 
 enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
 
@@ -220,6 +220,32 @@ int moc_train_steps_dp(const moc_batch_t* B, const moc_meta_t* M, const moc_meta
                        const int64_t* labels, int slide0, int n, uint32_t use_bits,
                        float* grad_flat, int64_t grad_count, moc_allreduce_fn allreduce,
                        void* comm, int world, moc_stream_t stream);
+
+/* e, one node: the same synchronous step with the exchange INSIDE the step kernel.  Every rank
+ * writes its gradient straight into its peers' receive buffers over xGMI (IPC-mapped, fine-grained
+ * memory), flags them, and sums the slices in rank order before its Adam update: two launches per
+ * step instead of three plus a collective, bit-identical parameters on every rank.
+ *   moc_p2p_create   allocate this rank's receive buffer for n_par = 64*D + 324 floats (current device)
+ *   moc_p2p_export   write moc_p2p_handle_bytes() bytes the peers need (exchange them out of band,
+ *                    e.g. torch.distributed.all_gather_object)
+ *   moc_p2p_connect  `blobs` = the world's exports concatenated in rank order
+ *   moc_p2p_allreduce  stand-alone sum of buf[0..n) over the ranks (self-check / small vectors)
+ *   moc_p2p_error    0, or 1 + the rank that stayed silent past the time-out (5 s; MOC_P2P_TIMEOUT_MS)
+ * Every rank must issue the same sequence of exchanges.  Ranks must be on one node, world <= 8. */
+typedef struct moc_p2p moc_p2p_t;
+int moc_p2p_handle_bytes(void);
+int moc_p2p_create(int world, int rank, int64_t n_par, moc_p2p_t** out);
+int moc_p2p_export(moc_p2p_t* comm, void* blob);
+int moc_p2p_connect(moc_p2p_t* comm, const void* blobs);
+int moc_p2p_allreduce(moc_p2p_t* comm, float* buf, int64_t n, moc_stream_t stream);
+int moc_p2p_error(moc_p2p_t* comm);
+int moc_p2p_destroy(moc_p2p_t* comm);
+/* 1 when moc_train_steps_p2p handles these run constants (a function of them alone, so that every
+ * rank takes the same decision whatever its bag sizes) */
+int moc_p2p_step_supported(int C, int topk, int D, int topj);
+int moc_train_steps_p2p(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
+                        const int64_t* labels, int slide0, int n, uint32_t use_bits,
+                        moc_p2p_t* comm, moc_stream_t stream);
 
 /* a10-a15 fused: `n` consecutive meta-steps (one slide each, slides slide0..slide0+n-1 in
  * order, one Adam step per slide: main_moc.py:380-410), parameters and Adam moments

@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 MOC_F32, MOC_BF16 = 0, 1
 SEL_BITS = {"topk": 1, "delta_softmax": 2, "delta_diff": 4, "bottomk": 8}
@@ -72,6 +72,15 @@ SIGNATURES = {
     "moc_train_steps": (C.c_int, [_BP, _MP, _WP, _p, C.c_int, C.c_int, C.c_uint32, _p]),
     "moc_train_steps_dp": (C.c_int, [_BP, _MP, _WP, _p, C.c_int, C.c_int, C.c_uint32, _p, C.c_int64, _p, _p,
                                      C.c_int, _p]),
+    "moc_p2p_handle_bytes": (C.c_int, []),
+    "moc_p2p_create": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
+    "moc_p2p_export": (C.c_int, [_p, _p]),
+    "moc_p2p_connect": (C.c_int, [_p, _p]),
+    "moc_p2p_allreduce": (C.c_int, [_p, _p, C.c_int64, _p]),
+    "moc_p2p_error": (C.c_int, [_p]),
+    "moc_p2p_destroy": (C.c_int, [_p]),
+    "moc_p2p_step_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "moc_train_steps_p2p": (C.c_int, [_BP, _MP, _WP, _p, C.c_int, C.c_int, C.c_uint32, _p, _p]),
     "moc_topk_mean": (C.c_int, [_p, C.c_int64, _p, C.c_int64, _p, _p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, _p, _p, _p, _p]),
 }

@@ -17,6 +17,7 @@
 //   -> finish (1 workgroup: CE, pair gradients, Adam on b1/W2/b2)
 //   -> w1_update (W1 gradient from <= K*C gathered rows + Adam, one thread per element)
 #include "moc_common.h"
+#include "moc_p2p.h"
 
 int moc_check_batch(const moc_batch_t* B, const char* who);
 int moc_launch_topk_mean(const float* keys, int64_t key_stride, const float* vals, int64_t val_stride,
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
 // They go to a short LDS list per class, and one wave per class extracts them in value order
 // (K wave-wide max reductions over the short list, DPP row operations, no LDS round trips).
 constexpr int PS_VPT = 4;       // values per thread per class  (S <= 4096)
+constexpr int FS_MAX_DYN_LDS = 160 * 1024 - 64;   // the step kernel also holds a few static LDS words
 constexpr int FS_MAX_XS = 20480; // one-launch step: pair rows staged in LDS, C*K*D <= this many floats (80 KiB)
 constexpr int PS_CAP_MAX = 1024; // candidate list entries per class (the launch picks cap <= this)
 
@@ -710,6 +712,7 @@ struct FusedArgs {
     unsigned char* W1img;
     float* W2out;
     int img_bf16;
+    P2pArgs x;              // world > 1: sum the gradient over the node's ranks before the update
 };
 
 
@@ -812,25 +815,86 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
     }
     __syncthreads();
     MOC_STAMP(17);
-    // ---- W1: gradient of the owned elements and their Adam step (parameter, moments, operand image)
+    // ---- gradients of the owned elements: 2x2 of W1 per thread, one of b1 / W2 / b2 in workgroup 0
+    const int ha = h_lo + hh * 2;
+    float gr[2][2] = {{0.f, 0.f}, {0.f, 0.f}};           // [d sweep][h sub-index]
     if (own) {
 #pragma unroll
         for (int sw = 0; sw < 2; ++sw) {
             const int d = dl + sw * dcols;
             if (d < D) {
                 float g0 = 0.f, g1 = 0.f;
-                const int ha = h_lo + hh * 2;
                 for (int p = 0; p < P; ++p) {
                     const float xv = xs[(size_t)p * D + d];
                     g0 = fmaf(dhs[p * H + ha], xv, g0);
                     g1 = fmaf(dhs[p * H + ha + 1], xv, g1);
                 }
-                const float gr[2] = {g0, g1};
+                gr[sw][0] = g0; gr[sw][1] = g1;
+            }
+        }
+    }
+    // tail element: flat order W1 | b1 | W2 | b2 (the order of the exchange slots)
+    float gt = 0.f;
+    int tail = -1;
+    if (wg == 0) {
+        if (t < 4 * H) {
+            const int i = t >> 6, h = t & 63;
+            for (int p = 0; p < P; ++p) gt = fmaf(dz[p * 4 + i], H1s[p * H + h], gt);
+            tail = H + t;
+        } else if (t < 4 * H + 4) {
+            const int i = t - 4 * H;
+            for (int p = 0; p < P; ++p) gt += dz[p * 4 + i];
+            tail = H + 4 * H + i;
+        } else if (t >= 320 && t < 320 + H) {
+            const int h = t - 320;
+            for (int p = 0; p < P; ++p) gt += dhs[p * H + h];
+            tail = h;
+        }
+    }
+    if (!a.apply_adam) {                                  // gradient out (data-parallel step with a collective)
+        if (own)
+            for (int sw = 0; sw < 2; ++sw) {
+                const int d = dl + sw * dcols;
+                if (d < D) { g.g_W1[(ha + 0) * D + d] = gr[sw][0]; g.g_W1[(ha + 1) * D + d] = gr[sw][1]; }
+            }
+        if (tail >= H + 4 * H) a.g_b2[tail - 5 * H] = gt;
+        else if (tail >= H) a.g_W2[tail - H] = gt;
+        else if (tail >= 0) a.g_b1[tail] = gt;
+        return;
+    }
+    if (g.x.world > 1) {                                  // one-shot exchange over xGMI (moc_p2p.h)
+        __shared__ int p2p_ok;
+        const int64_t nW1 = (int64_t)H * D;
+        if (own)
+#pragma unroll
+            for (int sw = 0; sw < 2; ++sw) {
+                const int d = dl + sw * dcols;
+                if (d < D) { p2p_push(g.x, (int64_t)(ha + 0) * D + d, gr[sw][0]); p2p_push(g.x, (int64_t)(ha + 1) * D + d, gr[sw][1]); }
+            }
+        if (tail >= 0) p2p_push(g.x, nW1 + tail, gt);
+        if (!p2p_signal_wait(g.x, wg, &p2p_ok)) return;   // time-out: reported through g.x.error, no update
+        if (own)
+#pragma unroll
+            for (int sw = 0; sw < 2; ++sw) {
+                const int d = dl + sw * dcols;
+                if (d < D) {
+                    gr[sw][0] = p2p_sum(g.x, (int64_t)(ha + 0) * D + d, gr[sw][0]);
+                    gr[sw][1] = p2p_sum(g.x, (int64_t)(ha + 1) * D + d, gr[sw][1]);
+                }
+            }
+        if (tail >= 0) gt = p2p_sum(g.x, nW1 + tail, gt);
+    }
+    // ---- Adam: parameter, moments, operand image
+    const float gs = a.adam.grad_scale;
+    if (own) {
+#pragma unroll
+        for (int sw = 0; sw < 2; ++sw) {
+            const int d = dl + sw * dcols;
+            if (d < D) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int e = (ha + j) * D + d;
-                    if (!a.apply_adam) { g.g_W1[e] = gr[j]; continue; }       // gradient out (data-parallel step)
-                    adam_update(pw[j][sw], pm[j][sw], pv[j][sw], gr[j] * a.adam.grad_scale, a.adam);
+                    adam_update(pw[j][sw], pm[j][sw], pv[j][sw], gr[sw][j] * gs, a.adam);
                     g.W1[e] = pw[j][sw]; g.m_W1[e] = pm[j][sw]; g.v_W1[e] = pv[j][sw];
                     if (g.img_bf16) w1_image_store_bf16(g.W1img, D, ha + j, d, pw[j][sw]);
                     else w1_image_store_f32(g.W1img, D, ha + j, d, pw[j][sw]);
@@ -838,37 +902,11 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
             }
         }
     }
-    // ---- workgroup 0: b1, W2 (into the other buffer), b2
-    if (wg == 0) {
-        const float gs = a.adam.grad_scale;
-        if (t < 4 * H) {
-            const int i = t >> 6, h = t & 63;
-            float gsum = 0.f;
-            for (int p = 0; p < P; ++p) gsum = fmaf(dz[p * 4 + i], H1s[p * H + h], gsum);
-            if (!a.apply_adam) a.g_W2[t] = gsum;
-            else {
-                adam_update(pW, pM, pV, gsum * gs, a.adam);
-                g.W2out[t] = pW; a.m_W2[t] = pM; a.v_W2[t] = pV;
-            }
-        } else if (t < 4 * H + 4) {
-            const int i = t - 4 * H;
-            float gsum = 0.f;
-            for (int p = 0; p < P; ++p) gsum += dz[p * 4 + i];
-            if (!a.apply_adam) a.g_b2[i] = gsum;
-            else {
-                adam_update(pW, pM, pV, gsum * gs, a.adam);
-                a.b2[i] = pW; a.m_b2[i] = pM; a.v_b2[i] = pV;
-            }
-        } else if (t >= 320 && t < 320 + H) {
-            const int h = t - 320;
-            float gsum = 0.f;
-            for (int p = 0; p < P; ++p) gsum += dhs[p * H + h];
-            if (!a.apply_adam) a.g_b1[h] = gsum;
-            else {
-                adam_update(pW, pM, pV, gsum * gs, a.adam);
-                a.b1[h] = pW; a.m_b1[h] = pM; a.v_b1[h] = pV;
-            }
-        }
+    if (tail >= 0) {                                      // workgroup 0: b1, W2 (into the other buffer), b2
+        adam_update(pW, pM, pV, gt * gs, a.adam);
+        if (tail >= H + 4 * H) { const int i = tail - 5 * H; a.b2[i] = pW; a.m_b2[i] = pM; a.v_b2[i] = pV; }
+        else if (tail >= H) { const int i = tail - H; g.W2out[i] = pW; a.m_W2[i] = pM; a.v_W2[i] = pV; }
+        else { a.b1[tail] = pW; a.m_b1[tail] = pM; a.v_b1[tail] = pV; }
     }
     MOC_STAMP(18);
 }
@@ -1105,13 +1143,14 @@ bool fused_step_ok(const moc_batch_t* B, const moc_meta_ws_t* ws) {
     if (!fused_ok(B, 1) || !ws->W2_alt) return false;
     if (B->D > 1024 || (int64_t)B->C * B->topk * B->D > FS_MAX_XS) return false;
     const int cap = B->C <= 8 ? PS_CAP_MAX : PS_CAP_MAX / 2;
-    return fused_step_smem(B, cap) <= 160 * 1024;
+    return fused_step_smem(B, cap) <= FS_MAX_DYN_LDS;
 }
 
 int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels,
                       int slide, uint32_t use_bits, const AdamCoef& k, float* W2out, hipStream_t s,
-                      int apply_adam = 1) {
+                      int apply_adam = 1, const P2pArgs* x = nullptr) {
     FusedArgs g = {};
+    if (x) g.x = *x;
     FinishArgs& a = g.f;
     a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel; a.cand = B->cand;
     a.H1 = ws->H1; a.gates = ws->gates; a.pooled = ws->pooled; a.mixed_in = ws->mixed;
@@ -1133,7 +1172,8 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
     const size_t smem = fused_step_smem(B, cap);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)pool_w1_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (hipFuncSetAttribute((const void*)pool_w1_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS) != hipSuccess)
+            MOC_FAIL(MOC_ELAUNCH, "moc_fused_step: cannot raise the dynamic LDS limit to %d bytes", FS_MAX_DYN_LDS);
         attr_set = true;
     }
     pool_w1_step_kernel<<<H / 4, 1024, smem, s>>>(g, ws->pooled, ws->topk_idx, ws->topk_cnt, cap);
@@ -1270,6 +1310,49 @@ extern "C" int moc_train_steps_dp(const moc_batch_t* B, const moc_meta_t* M, con
         const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f / (float)world);
         adam_all_kernel<<<moc_cdiv(n_par, 256), 256, 0, s>>>(*M, M->D, k, (unsigned char*)M->W1_image, img_bf16);
         MOC_CHECK_LAUNCH("moc_train_steps_dp");
+    }
+    return MOC_OK;
+}
+
+extern "C" int moc_p2p_step_supported(int C, int topk, int D, int topj) {
+    // from the run's constants only (not the bag sizes): every rank must take the same path
+    moc_batch_t B = {};
+    B.C = C; B.topk = topk; B.D = D; B.topj = topj; B.max_rows = 0x7fffffff;
+    moc_meta_ws_t ws = {};
+    float dummy;
+    ws.W2_alt = &dummy;
+    return C >= 1 && topk >= 1 && D >= 1 && topj >= 1 && fused_step_ok(&B, &ws) ? 1 : 0;
+}
+
+extern "C" int moc_train_steps_p2p(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
+                                   const int64_t* labels, int slide0, int n, uint32_t use_bits,
+                                   moc_p2p_t* comm, moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_train_steps_p2p")) return rc;
+    if (int rc = check_meta(B, M, ws, "moc_train_steps_p2p", true, false)) return rc;
+    MOC_REQUIRE(labels && slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_train_steps_p2p: bad labels/slide range");
+    MOC_REQUIRE(comm, "moc_train_steps_p2p: null communicator");
+    MOC_REQUIRE(fused_step_ok(B, ws), "moc_train_steps_p2p: shape outside the one-launch step (C<=16, K<=16, C*K*D<=%d); "
+                "use moc_train_steps_dp", FS_MAX_XS);
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = launch_w1_image(B, M, s)) return rc;
+    moc_meta_t Mt = *M;
+    float* cur = M->W2;
+    float* nxt = ws->W2_alt;
+    for (int t = 0; t < n; ++t) {
+        const int b = slide0 + t;
+        P2pArgs x;
+        if (int rc = moc_p2p_next_args(comm, &x)) return rc;
+        MOC_REQUIRE(x.n_par == (int64_t)H * M->D + H + 4 * H + 4, "moc_train_steps_p2p: communicator made for %lld parameters",
+                    (long long)x.n_par);
+        const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f / (float)x.world);
+        Mt.W2 = cur;
+        if (int rc = launch_forward(B, &Mt, ws, b, 1, use_bits, s)) return rc;
+        if (int rc = launch_fused_step(B, &Mt, ws, labels, b, use_bits, k, nxt, s, 1, &x)) return rc;
+        float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (cur != M->W2) {
+        if (hipMemcpyAsync(M->W2, cur, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            MOC_FAIL(MOC_ELAUNCH, "moc_train_steps_p2p: copy-back of W2 failed");
     }
     return MOC_OK;
 }

@@ -107,7 +107,97 @@ class DirectRccl:
             self.comm, self.ok = self.C.c_void_p(), False
 
 
+class P2pExchange:
+    """The node-local one-shot exchange of include/moc_hip.h (moc_p2p_*): every rank maps its peers'
+    fine-grained receive buffers (hipIpc handles travel through torch.distributed) and the step
+    kernel itself pushes, flags, waits and sums.  Set-up is collective and ends with a self-check
+    against torch.distributed's all-reduce; `ok` is the same on every rank (all must agree)."""
+
+    def __init__(self, device, n_par: int, group=None):
+        import ctypes as C
+        import socket
+        from ._lib import lib, check
+        self.C, self.lib, self.check = C, lib(), check
+        self.handle = C.c_void_p()
+        self.ok = False
+        self.why = ""
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_par = int(n_par)
+        mine_ok, blob = 1, b""
+        try:
+            assert self.world <= 8, "more than 8 ranks"
+            torch.cuda.set_device(device)
+            check(self.lib.moc_p2p_create(self.world, self.rank, self.n_par, C.byref(self.handle)), "moc_p2p_create")
+            nb = self.lib.moc_p2p_handle_bytes()
+            buf = C.create_string_buffer(nb)
+            check(self.lib.moc_p2p_export(self.handle, buf), "moc_p2p_export")
+            blob = buf.raw
+        except Exception as e:  # noqa: BLE001 (set-up only)
+            mine_ok, self.why = 0, f"create/export: {e}"
+        box = [None] * self.world
+        dist.all_gather_object(box, (mine_ok, socket.gethostname(), blob, self.why), group=group)
+        if not all(b[0] for b in box):
+            self.why = "; ".join(f"rank {i}: {b[3]}" for i, b in enumerate(box) if not b[0])
+        elif len({b[1] for b in box}) != 1:
+            self.why = "ranks span more than one node"
+        else:
+            try:
+                check(self.lib.moc_p2p_connect(self.handle, b"".join(b[2] for b in box)), "moc_p2p_connect")
+                mine_ok = 1
+            except Exception as e:  # noqa: BLE001
+                mine_ok, self.why = 0, f"connect: {e}"
+            # self-check on a known vector (also proves every rank reached this point with a live mapping)
+            flag = torch.tensor([mine_ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 1:
+                a = (torch.arange(1, self.n_par + 1, dtype=torch.float32, device=device) % 1021) * (self.rank + 1)
+                b = a.clone()
+                self.all_reduce_(a)
+                dist.all_reduce(b, group=group)
+                torch.cuda.synchronize()
+                good = int(torch.equal(a, b)) and self.error() == 0
+                flag.fill_(good)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                self.ok = int(flag.item()) == 1
+                if not self.ok:
+                    self.why = "self-check against torch.distributed failed on some rank"
+            elif not self.why:
+                self.why = "a peer could not map the buffers"
+        if not self.ok:
+            import warnings
+            warnings.warn(f"peer-to-peer gradient exchange unavailable ({self.why}); using the collective")
+
+    def all_reduce_(self, flat: torch.Tensor):
+        self.check(self.lib.moc_p2p_allreduce(self.handle, flat.data_ptr(), flat.numel(),
+                                              torch.cuda.current_stream().cuda_stream), "moc_p2p_allreduce")
+
+    def error(self) -> int:
+        return int(self.lib.moc_p2p_error(self.handle))
+
+    def close(self):
+        if self.handle:
+            self.lib.moc_p2p_destroy(self.handle)
+            self.handle, self.ok = self.C.c_void_p(), False
+
+
 _direct = {}
+_p2p = {}
+
+
+def p2p_exchange(device, n_par: int, group=None):
+    """The communicator for (group, device, n_par), created on first use (collective!).  None when
+    MOC_DP_EXCHANGE=rccl, outside a process group, at world 1 or when the set-up self-check failed."""
+    import os
+    if os.environ.get("MOC_DP_EXCHANGE", "auto") == "rccl" or not dist.is_initialized():
+        return None
+    if dist.get_world_size(group) == 1 or dist.get_world_size(group) > 8:
+        return None
+    key = (id(group), torch.device(device).index, int(n_par))
+    x = _p2p.get(key)
+    if x is None:
+        x = _p2p[key] = P2pExchange(device, n_par, group)
+    return x if x.ok else None
 
 
 def meta_grad_allreduce(flat: torch.Tensor, group=None):
@@ -156,10 +246,26 @@ def allreduce_entry(flat: torch.Tensor, group=None):
     return C.cast(fn, C.c_void_p), None, fn
 
 
+def exchange_error() -> int:
+    """0, or 1 + the rank whose push did not arrive within the time-out in some exchange so far
+    (meaningful after a synchronize; the pass it happened in must be discarded)."""
+    for x in _p2p.values():
+        if x.handle and x.error():
+            return x.error()
+    return 0
+
+
 def shutdown():
     for d in _direct.values():
         d.close()
     _direct.clear()
+    if _p2p:
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()          # nobody unmaps while a peer may still push
+    for x in _p2p.values():
+        x.close()
+    _p2p.clear()
 
 
 def allreduce_mean_(flat: torch.Tensor, group=None) -> float:
@@ -226,11 +332,20 @@ def train_dp(model, loader, optimizer, device, args, group=None):
         setattr(meta.c, name, v.data_ptr())
     batch.phase_a(bank)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    # the whole pass is ONE call: per step forward, pool+loss+gradients, the ONE collective (the
-    # flat gradient), Adam with 1/world -- the host loop lives in C (moc_train_steps_dp)
-    fn, comm, keep = allreduce_entry(fg.flat, group)
-    engine.train_steps_dp(batch, meta, lab, 0, len(sizes), use, fg.flat, fn, comm, world)
-    del keep
+    # the whole pass is ONE call, the host loop lives in C.  On one node the exchange happens inside
+    # the step kernel (moc_train_steps_p2p: forward + step, two launches); otherwise per step
+    # forward, pool+loss+gradients, the ONE collective (the flat gradient), Adam with 1/world.
+    x = p2p_exchange(device, fg.flat.numel(), group) if (fg.flat.is_cuda and engine.fused_step_shape(batch)) else None
+    if x is not None:
+        if x.error():
+            raise RuntimeError(f"peer-to-peer exchange: rank {x.error() - 1} stayed silent past the time-out in an earlier pass")
+        engine.train_steps_p2p(batch, meta, lab, 0, len(sizes), use, x.handle)
+        train_dp.exchange = "p2p"
+    else:
+        fn, comm, keep = allreduce_entry(fg.flat, group)
+        engine.train_steps_dp(batch, meta, lab, 0, len(sizes), use, fg.flat, fn, comm, world)
+        del keep
+        train_dp.exchange = "collective"
     meta.advance(len(sizes))            # the optimizer's own step counters, once per pass
     train_dp.last = (batch, lab, fg)
 

@@ -299,6 +299,21 @@ def train_steps_dp(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, sli
                                    _stream()), "moc_train_steps_dp")
 
 
+def fused_step_shape(batch: SlideBatch) -> bool:
+    """Whether the node-local exchange step applies -- decided from C, topk, D, topj only."""
+    c = batch.c
+    return bool(lib().moc_p2p_step_supported(c.C, c.topk, c.D, c.topj))
+
+
+def train_steps_p2p(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, slide0: int, n: int, use_bits: int,
+                    comm_handle):
+    """n synchronous data-parallel steps with the gradient exchange inside the step kernel
+    (moc_p2p_*: peer-mapped receive buffers on one node).  Does not advance the step counters."""
+    _, ws = batch.meta_ws()
+    check(lib().moc_train_steps_p2p(C.byref(batch.c), C.byref(meta.c), C.byref(ws), ptr(labels), slide0, n,
+                                    use_bits, comm_handle, _stream()), "moc_train_steps_p2p")
+
+
 def train_grad(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, slide: int, use_bits: int):
     """Forward + loss + gradients of one slide into meta.grads (no update)."""
     _, ws = batch.meta_ws()

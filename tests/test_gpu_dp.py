@@ -1,6 +1,8 @@
 """The data-parallel trainer end to end on the GPU: 2 ranks (gloo, both on cuda:0 -- the box has one
 GPU; the collective backend is not what is under test) against the oracle doing synchronous
-minibatch steps of 2 slides.  Also the sharded evaluation gather."""
+minibatch steps of 2 slides -- once with the gradient exchange inside the step kernel (peer-mapped
+receive buffers, moc_p2p_*), once with the all-reduce between the launches.  Also the sharded
+evaluation gather."""
 import os
 import socket
 
@@ -18,9 +20,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+SIZES = [900, 1100, 1000, 800, 950, 1050, 700, 1200]      # 2 ranks x 4 synchronous steps
+T = len(SIZES) // 2
+
+
+def _worker(rank, world, port, q, exchange):
     try:
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          MOC_DP_EXCHANGE=exchange, MOC_P2P_TIMEOUT_MS="20000")
         import torch.distributed as dist
         import helpers as H
         from moc_amd import main_moc as M, synth, dist as mdist
@@ -29,9 +36,9 @@ def _worker(rank, world, port, q):
         dev = torch.device("cuda:0")
         C, j, K = 2, 100, 10
         W, We = synth.make_bank(77, 512, C)
-        sizes = [900, 1100, 1000, 800]
+        sizes = SIZES
         bags, labels = synth.make_slide_set(7700, sizes, 512, We, C)
-        mine = [rank, rank + 2]                                   # step t uses slide t of every rank
+        mine = [rank + 2 * t for t in range(T)]                   # step t uses slide t of every rank
         torch.manual_seed(5)
         model = M.senet(512, 4).to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
@@ -40,22 +47,27 @@ def _worker(rank, world, port, q):
         torch.manual_seed(100 + rank)                             # each rank draws its own masks
         mdist.train_dp(model, res, opt, dev, H.make_args(C, j, K))
         torch.cuda.synchronize()
+        assert mdist.exchange_error() == 0
         losses = mdist.train_dp.last[0].meta_ws()[0]["loss"].cpu().numpy()
-        ev = mdist.evaluation_dp(model, res, dev, H.make_args(C, j, K), labels, mine, [[0, 2], [1, 3]])
-        q.put((rank, (H.flat_params(model), losses, ev, int(float(opt.state[next(model.parameters())]["step"])))))
+        ev = mdist.evaluation_dp(model, res, dev, H.make_args(C, j, K), labels, mine,
+                                 [[2 * t for t in range(T)], [1 + 2 * t for t in range(T)]])
+        q.put((rank, (H.flat_params(model), losses, ev, int(float(opt.state[next(model.parameters())]["step"])),
+                      mdist.train_dp.exchange)))
+        mdist.shutdown()
         dist.destroy_process_group()
     except Exception:  # noqa: BLE001
         import traceback
         q.put((rank, "ERR " + traceback.format_exc()))
 
 
-def test_train_dp_two_ranks_matches_batch2_oracle(gpu_device):
+@pytest.mark.parametrize("exchange", ["auto", "rccl"])
+def test_train_dp_two_ranks_matches_batch2_oracle(gpu_device, exchange):
     import helpers as H
     from moc_amd import synth
     from oracle import moc_oracle as O
     ctx = mp.get_context("spawn")
     q, port = ctx.Queue(), _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     out = dict(q.get(timeout=300) for _ in range(2))
@@ -64,22 +76,24 @@ def test_train_dp_two_ranks_matches_batch2_oracle(gpu_device):
     for r, v in out.items():
         assert not isinstance(v, str), f"rank {r}: {v}"
     assert np.array_equal(out[0][0], out[1][0]), "ranks hold different parameters after the all-reduced steps"
-    assert out[0][3] == 2 and out[1][3] == 2
-    # oracle: two synchronous steps, each the mean gradient of one slide per rank
+    assert out[0][3] == T and out[1][3] == T
+    # the path asked for is the path taken (auto = the in-kernel exchange on one node)
+    assert out[0][4] == out[1][4] == ("p2p" if exchange == "auto" else "collective")
+    # oracle: T synchronous steps, each the mean gradient of one slide per rank
     C, j, K = 2, 100, 10
     W, We = synth.make_bank(77, 512, C)
-    sizes = [900, 1100, 1000, 800]
+    sizes = SIZES
     bags, labels = synth.make_slide_set(7700, sizes, 512, We, C)
     masks = {}
     for rank in range(2):
         torch.manual_seed(100 + rank)
-        for i in (rank, rank + 2):
+        for i in [rank + 2 * t for t in range(T)]:
             masks[i] = O.draw_mask(sizes[i])
     torch.manual_seed(5)
     ref = O.Senet(512, 4)
     ropt = O.make_optimizer(ref)
     ref_losses = {}
-    for t in range(2):
+    for t in range(T):
         grads = []
         for rank in range(2):
             i = rank + 2 * t
@@ -92,8 +106,8 @@ def test_train_dp_two_ranks_matches_batch2_oracle(gpu_device):
             p.grad = (g0 + g1) / 2
         ropt.step()
     for rank in range(2):
-        np.testing.assert_allclose(out[rank][1], [ref_losses[rank], ref_losses[rank + 2]], atol=1e-4)
-    H.assert_adam_params_close(out[0][0], H.flat_params(ref), H.flat_state(ropt, "exp_avg_sq"), step=2,
+        np.testing.assert_allclose(out[rank][1], [ref_losses[rank + 2 * t] for t in range(T)], atol=1e-4)
+    H.assert_adam_params_close(out[0][0], H.flat_params(ref), H.flat_state(ropt, "exp_avg_sq"), step=T,
                                grad_noise=1e-6, what="dp2")
     ev_ref = O.evaluation(ref, bags, labels, W, We, C, j, K)
     for rank in range(2):
