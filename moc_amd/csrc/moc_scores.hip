@@ -132,6 +132,61 @@ __device__ __forceinline__ void row_epilogue(const ScoresArgs& a, const float* t
     (void)ldt;
 }
 
+// all 64 lanes: lane = (part, row) with part = lane >> 4 owning columns part, part + 4, ...; the row's
+// values are read from the wave's tile in one batch of independent LDS reads, the four partial results of
+// a row meet through two xor-shuffles (commutative pairings: every lane of a row gets the same bits)
+template <int NT>
+__device__ __forceinline__ void row_epilogue_wide(const ScoresArgs& a, const float* tile, int64_t slot_base,
+                                                  int row0, int nk) {
+    constexpr int LDT = NT * 16 + 1, Q = NT * 4;
+    const int lane = threadIdx.x & 63, row = lane & 15, part = lane >> 4;
+    const int C = a.C, Ce = a.Ce;
+    float v[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[q] = tile[row * LDT + q * 4 + part];
+    float m1 = -INFINITY, m2 = -INFINITY, bsum = 0.f, bmax = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int c = q * 4 + part;
+        if (c < C) {
+            if (v[q] > m1) { m2 = m1; m1 = v[q]; } else if (v[q] > m2) { m2 = v[q]; }
+        } else if (c < Ce) {
+            bsum += v[q];
+            bmax = fmaxf(bmax, v[q]);
+        }
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        const float o1 = __shfl_xor(m1, off, 64), o2 = __shfl_xor(m2, off, 64);
+        m2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));          // duplicates of the maximum count (gap 0), as topk(2)
+        m1 = fmaxf(m1, o1);
+        bsum += __shfl_xor(bsum, off, 64);
+        bmax = fmaxf(bmax, __shfl_xor(bmax, off, 64));
+    }
+    float e[Q], den = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        e[q] = (q * 4 + part < C) ? expf(v[q] - m1) : 0.f;
+        den += e[q];
+    }
+    den += __shfl_xor(den, 16, 64);
+    den += __shfl_xor(den, 32, 64);
+    if (row0 + row >= nk) return;
+    float* s = a.stats + slot_base + row0 + row;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int c = q * 4 + part;
+        if (c < C) {
+            s[(int64_t)c * a.stride] = v[q];
+            s[(int64_t)(C + c) * a.stride] = e[q] / den;
+        }
+    }
+    if (part == 0) s[(int64_t)(2 * C) * a.stride] = fabsf(m1 - m2);
+    else if (part == 1) s[(int64_t)(2 * C + 1) * a.stride] = bsum;
+    else if (part == 2) s[(int64_t)(2 * C + 2) * a.stride] = bmax;
+    else a.sel_flag[slot_base + row0 + row] = 0;
+}
+
 // CH = elements of K held in registers per chunk (512 or 256).  BF16: bf16 bag.
 template <int CH, bool BF16>
 __global__ __launch_bounds__(256) void scores_kernel(ScoresArgs a) {
@@ -247,6 +302,49 @@ __device__ __forceinline__ void asm_wait_keep(u32x4_t (&buf)[NF]) {
     asm_touch<0, NF>(buf);
 }
 
+// LDS reads of the B fragments, issued and awaited by hand for the same reason: left to hipcc, every
+// ds_read_b128 sinks next to the MFMA that uses it (read, wait, MFMA, 144 times per tile at NT = 3) and
+// with one workgroup per CU nothing hides that latency.  LDS returns in order, so after issuing batch
+// n+1, "lgkmcnt(size of batch n+1)" means batch n has landed.  No scalar load is outstanding inside
+// compute() (locate() consumes its own), so lgkmcnt counts only these reads.
+template <int OFF>
+__device__ __forceinline__ void asm_lds16(u32x4_t& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int KEEP, int NB>
+__device__ __forceinline__ void asm_lds_wait_keep(u32x4_t (&buf)[NB]) {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(KEEP) : "memory");
+    asm_touch<0, NB>(buf);
+}
+// batch of B fragments for A fragment F: PER reads (terms) at F*PER*1024 + t*1024 from each of NT bases
+template <int F, int PER, int NT, int I, int NB>
+__device__ __forceinline__ void asm_lds_batch(u32x4_t (&Bv)[NB], const unsigned (&base)[NT]) {
+    if constexpr (I < PER * NT) {
+        constexpr int t = I / NT, nt = I % NT;
+        asm_lds16<(F * PER + t) * 1024>(Bv[I], base[nt]);
+        asm_lds_batch<F, PER, NT, I + 1, NB>(Bv, base);
+    }
+}
+
+// two A fragments per step: issue the batch for F+1, wait for batch F, MFMAs of F; issue F+2, wait F+1, MFMAs
+template <int F, int NF, int PER, int NT, int NB, typename Mac>
+__device__ __forceinline__ void compute_pairs_impl(const u32x4_t (&buf)[NF], u32x4_t (&B0)[NB], u32x4_t (&B1)[NB],
+                                                   const unsigned (&base)[NT], Mac& mac) {
+    if constexpr (F < NF) {
+        asm_lds_batch<F + 1, PER, NT, 0, NB>(B1, base);
+        asm_lds_wait_keep<NB, NB>(B0);
+        mac(B0, buf[F]);
+        if constexpr (F + 2 < NF) {
+            asm_lds_batch<F + 2, PER, NT, 0, NB>(B0, base);
+            asm_lds_wait_keep<NB, NB>(B1);
+        } else {
+            asm_lds_wait_keep<0, NB>(B1);
+        }
+        mac(B1, buf[F + 1]);
+        compute_pairs_impl<F + 2, NF, PER, NT, NB>(buf, B0, B1, base, mac);
+    }
+}
+
 // ---- streaming form for Ct <= 16 (one n-tile): persistent workgroups ---------------
 // The generic kernel above leaves the load schedule to the compiler, which keeps two
 // 1-KiB loads in flight per wave (24 KB per CU: ~3 TB/s).  Here every wave walks a flat
@@ -254,26 +352,31 @@ __device__ __forceinline__ void asm_wait_keep(u32x4_t (&buf)[NF]) {
 // workgroup, and the A fragments are double buffered by hand: all NF loads of the NEXT
 // unit are issued before the MFMAs of the current one, so each wave keeps >= NF KiB in
 // flight.  A unit = NF*64 bytes of each of the tile's 16 rows (NF = 16: 1 KiB).
-template <int NF, bool BF16>
-__global__ __launch_bounds__(256, 2) void scores_stream_kernel(ScoresArgs a, int n_slides) {
+// NT n-tiles (Ct <= 16*NT) are accumulated side by side from ONE read of the A fragments, the whole
+// bank image (NT x img) resident in LDS: NT > 1 leaves room for one workgroup per CU only.
+// The launch covers slides [slide0, slide0 + n_slides) (the launcher chunks a batch whose per-slide
+// metadata would not fit beside the image).
+template <int NF, bool BF16, int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(ScoresArgs a, int slide0, int n_slides) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ESZ = BF16 ? 2 : 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row_bytes = (int64_t)a.D * ESZ;
     const int U = (int)(row_bytes / (NF * 64));                  // units per tile
     const int img_bytes = BF16 ? (a.D / 32) * 3 * 1024 : (a.D / 16) * 1024;
-    constexpr int LDT = 17;
+    constexpr int LDT = NT * 16 + 1;
+    const int img_vec = img_bytes / 16;                          // uint4 per n-tile
     uint4* lds_b = reinterpret_cast<uint4*>(smem);
-    float* tile = reinterpret_cast<float*>(smem + img_bytes) + wave * 16 * LDT;
+    float* tile = reinterpret_cast<float*>(smem + (size_t)NT * img_bytes) + wave * 16 * LDT;
     // [n_slides] first slot, [n_slides] first X row, [n_slides + 1] tile prefix, [n_slides] kept rows
-    int64_t* s_base = reinterpret_cast<int64_t*>(smem + img_bytes + 4 * 16 * LDT * sizeof(float));
+    int64_t* s_base = reinterpret_cast<int64_t*>(smem + (size_t)NT * img_bytes + 4 * 16 * LDT * sizeof(float));
     int64_t* s_xbase = s_base + n_slides;
     int* prefix = reinterpret_cast<int*>(s_xbase + n_slides);
     int* s_nk = prefix + n_slides + 1;
 
     {   // bank image -> LDS, four 16-B loads in flight per thread
         const uint4* src = reinterpret_cast<const uint4*>(a.bank);
-        const int nvec = img_bytes / 16;
+        const int nvec = NT * img_vec;
         int i = threadIdx.x;
         for (; i + 3 * 256 < nvec; i += 4 * 256) {
             const uint4 t0 = src[i], t1 = src[i + 256], t2 = src[i + 512], t3 = src[i + 768];
@@ -283,10 +386,10 @@ __global__ __launch_bounds__(256, 2) void scores_stream_kernel(ScoresArgs a, int
     }
     // per-slide metadata in LDS so that locating a tile costs no dependent global loads
     for (int b = threadIdx.x; b < n_slides; b += 256) {
-        const int64_t base = a.row_off[b];
+        const int64_t base = a.row_off[slide0 + b];
         s_base[b] = base;
-        s_xbase[b] = a.x_off ? a.x_off[b] : base;
-        s_nk[b] = a.kept ? a.n_kept[b] : (int)(a.row_off[b + 1] - base);
+        s_xbase[b] = a.x_off ? a.x_off[slide0 + b] : base;
+        s_nk[b] = a.kept ? a.n_kept[slide0 + b] : (int)(a.row_off[slide0 + b + 1] - base);
     }
     __syncthreads();
     if (wave == 0) {   // prefix[b] = tiles of slides < b
@@ -343,37 +446,49 @@ __global__ __launch_bounds__(256, 2) void scores_stream_kernel(ScoresArgs a, int
         u.kk0 = ch * NF;
         u.last = ch == U - 1;
     };
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](const u32x4_t (&buf)[NF], const Unit& u) {
-        if constexpr (BF16) {
-            const uint4* bp = lds_b + u.kk0 * 3 * 64 + lane;
+        // B fragments come from LDS one A fragment AHEAD of the MFMAs that use them (asm_lds_*)
+        constexpr int PER = BF16 ? 3 : 1;                       // 16-B B fragments per A fragment and n-tile
+        constexpr int NB = PER * NT;
+        static_assert(NB <= 15, "lgkmcnt is a 4-bit counter");
+        unsigned bbase[NT];                                    // LDS byte address of this unit's B rows, per n-tile
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const bf16x8_t A = __builtin_bit_cast(bf16x8_t, buf[f]);
+        for (int nt = 0; nt < NT; ++nt)
+            bbase[nt] = (unsigned)(uintptr_t)(lds_b + nt * img_vec + u.kk0 * PER * 64 + lane);
+        u32x4_t B0[NB], B1[NB];
+        auto mac = [&](const u32x4_t (&Bv)[NB], const u32x4_t& A) {
+            if constexpr (BF16) {
 #pragma unroll
-                for (int term = 0; term < 3; ++term) {
-                    const bf16x8_t Bv = __builtin_bit_cast(bf16x8_t, bp[(f * 3 + term) * 64]);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bv, acc, 0, 0, 0);
-                }
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)            // independent accumulators back to back
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, A),
+                                                                          __builtin_bit_cast(bf16x8_t, Bv[term * NT + nt]),
+                                                                          acc[nt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(A[m]), __uint_as_float(Bv[nt][m]),
+                                                                       acc[nt], 0, 0, 0);
             }
-        } else {
-            const uint4* bp = lds_b + u.kk0 * 64 + lane;
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const uint4 bv = bp[f * 64];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f][0]), __uint_as_float(bv.x), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f][1]), __uint_as_float(bv.y), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f][2]), __uint_as_float(bv.z), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(buf[f][3]), __uint_as_float(bv.w), acc, 0, 0, 0);
-            }
-        }
+        };
+        asm_lds_batch<0, PER, NT, 0, NB>(B0, bbase);
+        compute_pairs_impl<0, NF, PER, NT, NB>(buf, B0, B1, bbase, mac);
         if (u.last) {
             wave_lds_order();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tile[((lane >> 4) * 4 + i) * LDT + (lane & 15)] = acc[i];
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tile[((lane >> 4) * 4 + i) * LDT + nt * 16 + (lane & 15)] = acc[nt][i];
             wave_lds_order();
-            if (lane < 16) row_epilogue(a, tile + lane * LDT, LDT, u.base, u.row0 + lane, u.row0 + lane < u.nk);
-            acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            row_epilogue_wide<NT>(a, tile, u.base, u.row0, u.nk);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
     };
     // Flattened (tile, unit) walk, two register buffers.  The tile loads are inline asm so that the
@@ -643,11 +758,18 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
     const bool bf = B->dtype == MOC_BF16;
     const size_t img = bf ? (size_t)(B->D / 32) * 3 * 1024 : (size_t)(B->D / 16) * 1024;
     hipStream_t s = (hipStream_t)stream;
-    if (a.NT == 1) {
-        // streaming form: persistent workgroups over the flat tile list
+    // streaming form: persistent workgroups over the flat tile list, the whole bank image (all NT
+    // n-tiles) resident in LDS.  Applies while image + epilogue tiles + at least one slide's metadata fit.
+    const size_t fixed = (size_t)a.NT * img + 4 * 16 * (a.NT * 16 + 1) * sizeof(float) + 16;
+    // (bf16 stops at 3 n-tiles: with 4, the 12 B fragments per batch leave hipcc short of registers and it
+    // parks in-flight load destinations in AGPRs -- tests/test_isa_hazards_cpu.py)
+    if (a.NT <= (bf ? 3 : 4) && fixed + 24 <= 160 * 1024) {
         a.tpw = 0;
-        const size_t smem = img + 4 * 16 * 17 * sizeof(float) + (size_t)B->n_slides * 24 + 16;
-        MOC_REQUIRE(smem <= 160 * 1024, "moc_scores: D=%d / n_slides=%d need %zu B of LDS (> 160 KiB)", B->D, B->n_slides, smem);
+        const int chunk_max = (int)((160 * 1024 - fixed) / 24);
+        const int chunk = B->n_slides < chunk_max ? B->n_slides : chunk_max;
+        const size_t smem = fixed + (size_t)chunk * 24;
+        MOC_REQUIRE(a.NT > 1 || chunk == B->n_slides, "moc_scores: D=%d / n_slides=%d need %zu B of LDS (> 160 KiB)",
+                    B->D, B->n_slides, fixed + (size_t)B->n_slides * 24);
         int64_t tiles = 0;   // upper bound from the host-known sizes
         tiles = (B->total_rows + 15) / 16 + B->n_slides;
         int wgs = (int)((tiles + 3) / 4);
@@ -661,7 +783,7 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
         // rows of exactly one KiB unit only: with two units per row the two 32-register tile buffers no
         // longer fit beside the bank image, hipcc parks in-flight load destinations in AGPRs and the
         // data arriving later lands in registers that have been re-used (tests/test_isa_hazards_cpu.py)
-        const bool rows_ok = row_b == 1024;
+        const bool rows_ok = row_b == 1024 && a.NT == 1;
         if (rows_ok && variant && variant[0] == 'r') {
             const size_t smem2 = 4 * 16 * 1024 + 4 * 16 * 17 * sizeof(float) + (size_t)B->n_slides * 24 + 16;
             MOC_REQUIRE(smem2 <= 160 * 1024, "moc_scores: n_slides=%d needs %zu B of LDS (> 160 KiB)", B->n_slides, smem2);
@@ -682,22 +804,33 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
             MOC_CHECK_LAUNCH("moc_scores(rows)");
             return MOC_OK;
         }
-#define MOC_LAUNCH_STREAM(NF, BF)                                                                       \
+#define MOC_LAUNCH_STREAM(NF, BF, NTT)                                                                  \
         do {                                                                                            \
             static bool attr_set = false;                                                               \
             if (!attr_set) {                                                                            \
-                (void)hipFuncSetAttribute((const void*)scores_stream_kernel<NF, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                (void)hipFuncSetAttribute((const void*)scores_stream_kernel<NF, BF, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                 attr_set = true;                                                                        \
             }                                                                                           \
-            scores_stream_kernel<NF, BF><<<wgs, 256, smem, s>>>(a, B->n_slides);                        \
+            scores_stream_kernel<NF, BF, NTT><<<wgs, 256, smem, s>>>(a, s0, ns);                        \
         } while (0)
-        if (row_b % 1024 == 0) {
-            if (bf) MOC_LAUNCH_STREAM(16, true); else MOC_LAUNCH_STREAM(16, false);
-        } else {
-            if (bf) MOC_LAUNCH_STREAM(8, true); else MOC_LAUNCH_STREAM(8, false);
+#define MOC_LAUNCH_STREAM_NT(NF, BF)                                                                    \
+        do {                                                                                            \
+            if (a.NT == 1) MOC_LAUNCH_STREAM(NF, BF, 1);                                                \
+            else if (a.NT == 2) MOC_LAUNCH_STREAM(NF, BF, 2);                                           \
+            else if (a.NT == 3) MOC_LAUNCH_STREAM(NF, BF, 3);                                           \
+            else if constexpr (!BF) MOC_LAUNCH_STREAM(NF, BF, 4);                                       \
+        } while (0)
+        for (int s0 = 0; s0 < B->n_slides; s0 += chunk) {
+            const int ns = B->n_slides - s0 < chunk ? B->n_slides - s0 : chunk;
+            if (row_b % 1024 == 0) {
+                if (bf) MOC_LAUNCH_STREAM_NT(16, true); else MOC_LAUNCH_STREAM_NT(16, false);
+            } else {
+                if (bf) MOC_LAUNCH_STREAM_NT(8, true); else MOC_LAUNCH_STREAM_NT(8, false);
+            }
+            MOC_CHECK_LAUNCH("moc_scores(stream)");
         }
+#undef MOC_LAUNCH_STREAM_NT
 #undef MOC_LAUNCH_STREAM
-        MOC_CHECK_LAUNCH("moc_scores(stream)");
         return MOC_OK;
     }
     a.tpw = 1;

@@ -36,7 +36,8 @@ def _engine():
 
 # ------------------------------------------------------------------ score pass
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,C,D", [(1, 2, 512), (17, 2, 512), (1000, 3, 512), (4099, 30, 512), (700, 64, 1024), (333, 2, 256)])
+@pytest.mark.parametrize("N,C,D", [(1, 2, 512), (17, 2, 512), (1000, 3, 512), (4099, 30, 512), (700, 64, 1024), (333, 2, 256),
+                                   (2500, 20, 512), (1500, 50, 512), (900, 13, 256), (1100, 30, 1024)])
 def test_scores_and_row_stats_match_oracle(dev, dtype, N, C, D):
     E = _engine()
     W, We = synth.make_bank(100 + N, D, C)
@@ -54,6 +55,25 @@ def test_scores_and_row_stats_match_oracle(dev, dtype, N, C, D):
     np.testing.assert_allclose(st[2 * C + 1].numpy(), lge[:, C:].sum(1).numpy(), atol=4 * TIGHT, rtol=0)
     np.testing.assert_allclose(st[2 * C + 2].numpy(), lge[:, C:].max(1)[0].numpy(), atol=TIGHT, rtol=0)
     assert int(batch.sel_flag.sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scores_many_slides_wide_bank_is_chunked_consistently(dev, dtype):
+    """C = 30 keeps the whole 3-tile bank image in LDS, leaving room for ~160 slides' metadata: a
+    400-slide batch goes out in chunks and must give, row for row, what one long slide gives."""
+    E = _engine()
+    C, D = 30, 512
+    W, We = synth.make_bank(31, D, C)
+    sizes = [17 + (i * 37) % 90 for i in range(400)]
+    x = synth.make_bag(32, sum(sizes), D, We, C, label=3).to(dtype).to(dev).contiguous()
+    bank = E.Bank.get(W, We, dtype, dev)
+    many = E.SlideBatch(x, sizes, C, C + 4, 10, 10)
+    many.scores(bank)
+    one = E.SlideBatch(x, [sum(sizes)], C, C + 4, 10, 10)
+    one.scores(bank)
+    assert torch.equal(many.stats, one.stats)
+    xr = x.cpu().to(torch.float32)
+    np.testing.assert_allclose(many.stats[:C].t().cpu().numpy(), (xr @ W).numpy(), atol=TIGHT, rtol=0)
 
 
 def test_scores_uses_W_for_foreground_and_Wext_for_background(dev):

@@ -1,7 +1,9 @@
-"""Static check of the kernels that issue vector loads through inline asm (moc_scores.hip): between an
-asm `global_load_dwordx4 v[a:b], ...` and the hand-written `s_waitcnt vmcnt(N)` that covers it, no
-instruction may read or write v[a:b] -- the compiler does not know the data is still in flight, and
-under register pressure it has been seen to copy such registers away and re-use them."""
+"""Static check of the kernels that issue loads through inline asm (moc_scores.hip): between an asm
+`global_load_dwordx4 v[a:b], ...` / `ds_read_b128 v[a:b], ...` and the hand-written `s_waitcnt
+vmcnt(N)` / `lgkmcnt(N)` that covers it, no instruction may read or write v[a:b] -- the compiler does
+not know the data is still in flight, and under register pressure it has been seen to copy such
+registers away and re-use them.  Both counters retire in order, so a wait for N leaves
+exactly the N youngest loads of its kind in flight."""
 import os
 import re
 import subprocess
@@ -20,8 +22,12 @@ def _regs(tok):
     return {int(m.group(1))} if m else set()
 
 
-def _check_kernel(name, lines):
-    pending, in_asm, n_loads, n_waits = set(), False, 0, 0
+def _check_kernel(name, lines, precise=True):
+    """precise: a wait for N keeps the N youngest loads pending (valid where the textual order of the
+    ISA is the execution order between an issue and its wait: the streaming kernels).  Otherwise a wait
+    retires everything issued textually before it (the row kernel's rotated loop)."""
+    pend = {"vm": [], "lgkm": []}            # destination register sets, oldest first
+    in_asm, n_loads, n_waits = False, {"vm": 0, "lgkm": 0}, {"vm": 0, "lgkm": 0}
     for ln in lines:
         t = ln.strip()
         if t.startswith(";;#ASMSTART"):
@@ -33,18 +39,28 @@ def _check_kernel(name, lines):
         if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
             continue
         toks = re.findall(r"v\[\d+:\d+\]|v\d+", t)
-        if in_asm and t.startswith("global_load_dwordx4"):
-            pending |= _regs(toks[0])
-            n_loads += 1
+        kind = "vm" if t.startswith("global_load_dwordx4") else "lgkm" if t.startswith("ds_read_b128") else None
+        if in_asm and kind:
+            in_flight = set().union(*pend["vm"], *pend["lgkm"]) if (pend["vm"] or pend["lgkm"]) else set()
+            addr = set().union(*[_regs(x) for x in toks[1:]]) if len(toks) > 1 else set()
+            assert not (addr & in_flight), f"{name}: `{t}` takes its address from in-flight registers"
+            assert not (_regs(toks[0]) & in_flight), f"{name}: `{t}` overwrites registers still in flight"
+            pend[kind].append(_regs(toks[0]))
+            n_loads[kind] += 1
             continue
-        if in_asm and t.startswith("s_waitcnt vmcnt"):
-            pending.clear()          # every site issues the newer loads BEFORE this wait; those are
-            n_waits += 1             # re-armed below by the next asm loads, older ones are complete
+        m = re.match(r"s_waitcnt (vmcnt|lgkmcnt)\((\d+)\)", t)
+        if in_asm and m:
+            k = "vm" if m.group(1) == "vmcnt" else "lgkm"
+            keep = int(m.group(2))
+            pend[k] = pend[k][-keep:] if (keep and precise) else []
+            n_waits[k] += 1
             continue
         used = set()
         for tok in toks:
             used |= _regs(tok)
-        assert not (used & pending), f"{name}: `{t}` touches in-flight load registers {sorted(used & pending)[:8]}"
+        for k in pend:
+            for regs in pend[k]:
+                assert not (used & regs), f"{name}: `{t}` touches in-flight {k} load registers {sorted(used & regs)[:8]}"
     return n_loads, n_waits
 
 
@@ -67,5 +83,7 @@ def test_no_instruction_touches_inflight_asm_load_registers(tmp_path):
                 cur = None
     assert len(kernels) >= 4, f"expected the asm-load kernels in the ISA, found {list(kernels)}"
     for k, lines in kernels.items():
-        n_loads, n_waits = _check_kernel(k, lines)
-        assert n_loads >= 16 and n_waits >= 2, (k, n_loads, n_waits)
+        n_loads, n_waits = _check_kernel(k, lines, precise="scores_stream_kernel" in k)
+        assert n_loads["vm"] >= 16 and n_waits["vm"] >= 2, (k, n_loads, n_waits)
+        if "scores_stream_kernel" in k:
+            assert n_loads["lgkm"] >= 8 and n_waits["lgkm"] >= 8, (k, n_loads, n_waits)
