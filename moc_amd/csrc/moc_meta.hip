@@ -287,6 +287,8 @@ struct FinishArgs {
     AdamCoef adam;
 };
 
+constexpr int FIN_CHUNK = 256;   // pairs whose H1 rows are staged in LDS at a time (64 KiB)
+
 // grid (n): one workgroup per slide.  Eval: CE + argmax only.  Train (n == 1): also the
 // gradient "pairs" and the gradient/Adam of b1, W2, b2.
 __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
@@ -307,14 +309,22 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
         if (a.train) for (int c = 0; c < C; ++c) dpool[c] = expf(x[c] - lse) - (c == y ? 1.f : 0.f);
     }
     if (!a.train) return;
+    // Adam operands: requested now, consumed at the very end
+    float oW = 0.f, oM = 0.f, oV = 0.f, oW2 = 0.f, oM2 = 0.f, oV2 = 0.f;
+    if (a.apply_adam) {
+        const int tt = threadIdx.x;
+        oW = a.W2[tt]; oM = a.m_W2[tt]; oV = a.v_W2[tt];
+        if (tt < 4) { oW2 = a.b2[tt]; oM2 = a.m_b2[tt]; oV2 = a.v_b2[tt]; }
+        else if (tt >= 64 && tt < 64 + H) { oW2 = a.b1[tt - 64]; oM2 = a.m_b1[tt - 64]; oV2 = a.v_b1[tt - 64]; }
+    }
+    const int64_t base = a.row_off[b];
+    const int cnt = a.topk_cnt[(int64_t)b * C];
     __syncthreads();
 
-    const int64_t base = a.row_off[b];
     // pairs p = (c, r): r-th pooled row of class c.  n_pair = sum_c cnt[c] <= C*K
     float* dz = reinterpret_cast<float*>(smem);                 // [P][4]
     int* prow = reinterpret_cast<int*>(dz + (size_t)C * a.K * 4);   // [P] position s of the pair's row
     // every class pools the same number of rows: cnt = min(K, S)
-    const int cnt = a.topk_cnt[(int64_t)b * C];
     const int P = C * cnt;
     for (int p = threadIdx.x; p < P; p += 256) {
         const int c = p / cnt, r = p - c * cnt;
@@ -333,35 +343,65 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
         a.pair_row[p] = a.sel_row[base + s];
     }
     if (threadIdx.x == 0) *a.n_pair = P;
+    // H1 rows of the pairs go through LDS in chunks of FIN_CHUNK pairs (one coalesced round of gathers
+    // per chunk): read per element from global memory, the W2 / b1 reductions below were P dependent
+    // gathers long (68 us at C*K = 300).
+    float* H1s = reinterpret_cast<float*>(prow + (size_t)C * a.K);   // [FIN_CHUNK][H]
+    float* W2s = H1s + FIN_CHUNK * H;                                // [4][H]
+    const int t = threadIdx.x, h = t & 63, g4 = t >> 6;
+    W2s[t] = a.W2[t];
+    float gW2 = 0.f, gb1 = 0.f;                 // W2[g4][h]; partial of b1[h] over the pairs p = g4 (mod 4)
+    for (int c0 = 0; c0 < P; c0 += FIN_CHUNK) {
+        const int n = P - c0 < FIN_CHUNK ? P - c0 : FIN_CHUNK;
+        __syncthreads();                        // previous chunk consumed (first pass: dz / prow / W2s written)
+        for (int e0 = 0; e0 < n * H; e0 += 16 * 256) {          // 16 independent gathers in flight per thread
+            float r[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = e0 + q * 256 + t;
+                r[q] = e < n * H ? a.H1[(base + prow[c0 + (e >> 6)]) * H + h] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = e0 + q * 256 + t;
+                if (e < n * H) H1s[e] = r[q];
+            }
+        }
+        __syncthreads();
+        for (int pp = g4; pp < n; pp += 4) {    // dh[p][h] = (sum_i dz[p][i] * W2[i][h]) * [H1 > 0]
+            const float* dzp = dz + (size_t)(c0 + pp) * 4;
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v = fmaf(dzp[i], W2s[i * H + h], v);
+            v = H1s[pp * H + h] > 0.f ? v : 0.f;
+            a.pair_dh[(size_t)(c0 + pp) * H + h] = v;
+            gb1 += v;
+        }
+        for (int pp = 0; pp < n; ++pp) gW2 = fmaf(dz[(size_t)(c0 + pp) * 4 + g4], H1s[pp * H + h], gW2);
+    }
     __syncthreads();
-    // dh[p][h] = (sum_i dz[p][i] * W2[i][h]) * [H1 > 0]
-    for (int e = threadIdx.x; e < P * H; e += 256) {
-        const int p = e >> 6, h = e & 63;
-        float v = 0.f;
-        for (int i = 0; i < 4; ++i) v = fmaf(dz[p * 4 + i], a.W2[i * H + h], v);
-        a.pair_dh[e] = a.H1[(base + prow[p]) * H + h] > 0.f ? v : 0.f;
-    }
-    __syncthreads();   // W2 fully read (and pair_dh visible to this workgroup) before it is updated
+    H1s[t] = gb1;                               // b1[h] = the four partial sums, in a fixed order
+    __syncthreads();
     const float gs = a.adam.grad_scale;
-    {   // W2 [4][H]: thread t -> (i = t>>6, h = t&63)
-        const int i = threadIdx.x >> 6, h = threadIdx.x & 63;
+    if (a.apply_adam) {
+        adam_update(oW, oM, oV, gW2 * gs, a.adam);
+        a.W2[t] = oW; a.m_W2[t] = oM; a.v_W2[t] = oV;
+    } else a.g_W2[t] = gW2;
+    if (t < 4) {
         float g = 0.f;
-        for (int p = 0; p < P; ++p) g = fmaf(dz[p * 4 + i], a.H1[(base + prow[p]) * H + h], g);
-        if (a.apply_adam) adam_update(a.W2[threadIdx.x], a.m_W2[threadIdx.x], a.v_W2[threadIdx.x], g * gs, a.adam);
-        else a.g_W2[threadIdx.x] = g;
+        for (int p = 0; p < P; ++p) g += dz[p * 4 + t];
+        if (a.apply_adam) {
+            adam_update(oW2, oM2, oV2, g * gs, a.adam);
+            a.b2[t] = oW2; a.m_b2[t] = oM2; a.v_b2[t] = oV2;
+        } else a.g_b2[t] = g;
     }
-    if (threadIdx.x < 4) {
-        float g = 0.f;
-        for (int p = 0; p < P; ++p) g += dz[p * 4 + threadIdx.x];
-        if (a.apply_adam) adam_update(a.b2[threadIdx.x], a.m_b2[threadIdx.x], a.v_b2[threadIdx.x], g * gs, a.adam);
-        else a.g_b2[threadIdx.x] = g;
-    }
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + H) {
-        const int h = threadIdx.x - 64;
-        float g = 0.f;
-        for (int p = 0; p < P; ++p) g += a.pair_dh[p * H + h];
-        if (a.apply_adam) adam_update(a.b1[h], a.m_b1[h], a.v_b1[h], g * gs, a.adam);
-        else a.g_b1[h] = g;
+    if (t >= 64 && t < 64 + H) {
+        const int hh = t - 64;
+        const float g = ((H1s[hh] + H1s[64 + hh]) + H1s[128 + hh]) + H1s[192 + hh];
+        if (a.apply_adam) {
+            adam_update(oW2, oM2, oV2, g * gs, a.adam);
+            a.b1[hh] = oW2; a.m_b1[hh] = oM2; a.v_b1[hh] = oV2;
+        } else a.g_b1[hh] = g;
     }
 }
 
@@ -933,8 +973,9 @@ struct W1Args {
 constexpr int W1_MAXP = 64;
 template <bool BF16>
 __global__ __launch_bounds__(256) void w1_update_kernel(W1Args a) {
-    __shared__ float xs[W1_MAXP][256];
+    __shared__ __attribute__((aligned(16))) float xs[W1_MAXP][256];
     __shared__ float dh_s[W1_MAXP][8];
+    __shared__ int64_t prow_s[W1_MAXP];
     const int d = blockIdx.x * 256 + threadIdx.x, h0 = blockIdx.y * 8;
     MOC_STAMP(20);
     float pw[8], pm[8], pv[8];
@@ -954,11 +995,31 @@ __global__ __launch_bounds__(256) void w1_update_kernel(W1Args a) {
 #pragma unroll 8
             for (int p = 0; p < np; ++p) xs[p][threadIdx.x] = a.pair_x[(int64_t)(p0 + p) * a.D + d];
         } else {
-#pragma unroll 8
-            for (int p = 0; p < np; ++p) {
-                const int64_t row = a.pair_row[p0 + p];
-                if constexpr (BF16) xs[p][threadIdx.x] = moc_bf16_to_f32(reinterpret_cast<const uint16_t*>(a.X)[row * a.D + d]);
-                else xs[p][threadIdx.x] = reinterpret_cast<const float*>(a.X)[row * a.D + d];
+            // 16-B loads, all independent: LPR lanes cover one row's 256 columns, 256/LPR rows per round
+            if (threadIdx.x < np) prow_s[threadIdx.x] = a.pair_row[p0 + threadIdx.x];
+            __syncthreads();
+            constexpr int EPL = BF16 ? 8 : 4, LPR = 256 / EPL, RPR = 256 / LPR;   // elements/lane, lanes/row, rows/round
+            const int v = threadIdx.x % LPR, pr = threadIdx.x / LPR;
+            const int64_t col = (int64_t)blockIdx.x * 256 + v * EPL;
+#pragma unroll
+            for (int r = 0; r < W1_MAXP / RPR; ++r) {
+                const int p = r * RPR + pr;
+                if (p < np) {
+                    const int64_t row = prow_s[p];
+                    float* dst = &xs[p][v * EPL];
+                    if constexpr (BF16) {
+                        const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.X) + row * a.D + col);
+                        float4 lo, hi;
+                        lo.x = __uint_as_float(raw.x << 16); lo.y = __uint_as_float(raw.x & 0xFFFF0000u);
+                        lo.z = __uint_as_float(raw.y << 16); lo.w = __uint_as_float(raw.y & 0xFFFF0000u);
+                        hi.x = __uint_as_float(raw.z << 16); hi.y = __uint_as_float(raw.z & 0xFFFF0000u);
+                        hi.z = __uint_as_float(raw.w << 16); hi.w = __uint_as_float(raw.w & 0xFFFF0000u);
+                        reinterpret_cast<float4*>(dst)[0] = lo;
+                        reinterpret_cast<float4*>(dst)[1] = hi;
+                    } else {
+                        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.X) + row * a.D + col);
+                    }
+                }
             }
         }
         for (int e = threadIdx.x; e < np * 8; e += 256) dh_s[e >> 3][e & 7] = a.pair_dh[(p0 + (e >> 3)) * H + h0 + (e & 7)];
@@ -1084,8 +1145,14 @@ int launch_finish(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t
     a.pair_dh = ws->pair_dh; a.pair_row = ws->pair_row; a.n_pair = ws->n_pair;
     a.stride = B->total_rows; a.C = B->C; a.K = B->topk; a.slide0 = slide0; a.train = train;
     a.apply_adam = apply_adam; a.use_bits = use_bits; a.adam = k;
-    const size_t smem = train ? (size_t)B->C * B->topk * (4 * sizeof(float) + sizeof(int)) : 0;
-    MOC_REQUIRE(smem <= 64 * 1024, "finish: C*topk = %d too large", B->C * B->topk);
+    const size_t smem = train ? (size_t)B->C * B->topk * (4 * sizeof(float) + sizeof(int)) +
+                                (size_t)(FIN_CHUNK + 4) * H * sizeof(float) : 0;
+    MOC_REQUIRE(smem <= 159 * 1024, "finish: C*topk = %d too large", B->C * B->topk);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        attr_set = true;
+    }
     finish_kernel<<<n, 256, smem, s>>>(a);
     MOC_CHECK_LAUNCH("moc_finish");
     return MOC_OK;

@@ -190,14 +190,14 @@ struct TopkArgs {
 
 // grid (C, n_seg).  All LDS is dynamic (16-B aligned base): [P x u64 list][P x f32 vals][scratch ints],
 // P = K rounded up to a power of two.
-__global__ __launch_bounds__(256) void topk_mean_kernel(TopkArgs a) {
+__global__ __launch_bounds__(1024) void topk_mean_kernel(TopkArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int Pmax = 1;
     while (Pmax < a.K) Pmax <<= 1;
     float* lvals = reinterpret_cast<float*>(smem + (size_t)Pmax * 8);
     int* hist = reinterpret_cast<int*>(smem + (size_t)Pmax * 12);   // [260]
-    int* wave_tot = hist + 260;                                     // [8]
-    int& n_list = hist[268];
+    int* wave_tot = hist + 260;                                     // [17]
+    int& n_list = hist[280];
     const int c = blockIdx.x, seg = a.seg0 + blockIdx.y;
     const int64_t base = a.seg_off[seg];
     const int n = a.seg_len ? a.seg_len[seg] : (int)(a.seg_off[seg + 1] - base);
@@ -328,7 +328,8 @@ int moc_launch_topk_mean(const float* keys, int64_t key_stride, const float* val
     a.C = C; a.K = K; a.smallest = smallest; a.seg0 = seg0;
     int P = 1;
     while (P < K) P <<= 1;
-    topk_mean_kernel<<<dim3(C, n_seg), 256, (size_t)P * 12 + 272 * sizeof(int), s>>>(a);
+    // 1024 threads: the select passes are chains of dependent key reads, one per blockDim.x keys
+    topk_mean_kernel<<<dim3(C, n_seg), 1024, (size_t)P * 12 + 288 * sizeof(int), s>>>(a);
     MOC_CHECK_LAUNCH("moc_topk_mean");
     return MOC_OK;
 }
