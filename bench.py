@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1600)
     ap.add_argument("--warmup", type=int, default=160)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="bag STORAGE type; arithmetic is fp32")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"], help="bag STORAGE type; arithmetic is fp32")
     ap.add_argument("--slides", type=int, default=32, help="train slides per epoch (NSCLC 16-shot: 32)")
     ap.add_argument("--patches", type=int, default=15000)
     ap.add_argument("--classes", type=int, default=2)
@@ -90,7 +90,7 @@ def main():
     from moc_amd import dist as mdist
 
     C, D, j, K = a.classes, a.dim, a.topj, a.topk
-    store = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    store = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(a.dtype, torch.float32)
     W, We = synth.make_bank(1234, D, C)
     M.set_classifier_bank(W.to(dev), We.to(dev))
     sizes = synth.bag_sizes(99 + rank, a.slides, a.patches, fixed=not a.lognormal)

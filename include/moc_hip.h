@@ -33,12 +33,12 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 6
+#define MOC_ABI_VERSION 7
 
 enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
 
 /* storage type of the bag X; arithmetic is always fp32-accumulate */
-enum { MOC_F32 = 0, MOC_BF16 = 1 };
+enum { MOC_F32 = 0, MOC_BF16 = 1, MOC_F16 = 2 };
 
 /* bits of `discard_bits`, in the order of main_moc.py:341-350 */
 enum { MOC_SEL_TOPK = 1, MOC_SEL_DELTA_SOFTMAX = 2, MOC_SEL_DELTA_DIFF = 4, MOC_SEL_BOTTOMK = 8 };
@@ -51,7 +51,7 @@ typedef void* moc_stream_t; /* hipStream_t */
 typedef struct moc_batch {
     /* ---- inputs ---- */
     const void*    X;          /* device [total_rows, D]                                  */
-    int32_t        dtype;      /* MOC_F32 | MOC_BF16                                     */
+    int32_t        dtype;      /* MOC_F32 | MOC_BF16 | MOC_F16 (storage; arithmetic is fp32) */
     int32_t        D;          /* embedding dim (512 for CONCH)                          */
     int64_t        total_rows;
     int32_t        n_slides;

@@ -15,9 +15,9 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
-MOC_F32, MOC_BF16 = 0, 1
+MOC_F32, MOC_BF16, MOC_F16 = 0, 1, 2
 SEL_BITS = {"topk": 1, "delta_softmax": 2, "delta_diff": 4, "bottomk": 8}
 
 _p = C.c_void_p

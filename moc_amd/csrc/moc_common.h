@@ -8,6 +8,7 @@
 #define MOC_HIDDEN 64
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 // ---- host-side error plumbing ------------------------------------------------
@@ -46,6 +47,48 @@ __device__ __forceinline__ uint16_t moc_f32_to_bf16_rne(float f) {
     uint32_t u = __float_as_uint(f);
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
+}
+
+// ---- 16-bit bag storage (bf16 or fp16), fp32-exact products -------------------------------------
+// A weight is held as three 16-bit terms hi + mid + lo so that x * w is exact in the fp32 accumulator:
+//   bf16: the three terms of w itself (8+8+8 mantissa bits);
+//   fp16: the three terms of w * 2^S (11+11+2 bits) -- fp16 has 5 exponent bits, so the small terms of
+//         an unscaled weight would be subnormal; the accumulated product is scaled back by 2^-S (exact).
+//         S = 14 for the classifier bank (|w| < 2 is checked), 10 for the meta-learner's W1 (|w| < 32).
+#define MOC_F16_BANK_SCALE 16384.0f
+#define MOC_F16_W1_SCALE 1024.0f
+
+__device__ __forceinline__ uint16_t moc_f16_bits(_Float16 h) { return __builtin_bit_cast(uint16_t, h); }
+__device__ __forceinline__ float moc_f16_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+
+template <bool F16>
+__device__ __forceinline__ float moc_half_to_f32(uint16_t b) {
+    if constexpr (F16) return moc_f16_to_f32(b);
+    else return moc_bf16_to_f32(b);
+}
+
+// `scale` is applied for fp16 only
+template <bool F16>
+__device__ __forceinline__ void moc_split3(float w, float scale, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
+    if constexpr (F16) {
+        const float ws = w * scale;
+        const _Float16 h = (_Float16)ws;
+        const float r1 = ws - (float)h;
+        const _Float16 m = (_Float16)r1;
+        const _Float16 l = (_Float16)(r1 - (float)m);
+        hi = moc_f16_bits(h); mid = moc_f16_bits(m); lo = moc_f16_bits(l);
+    } else {
+        hi = moc_f32_to_bf16_rne(w);
+        const float r1 = w - moc_bf16_to_f32(hi);
+        mid = moc_f32_to_bf16_rne(r1);
+        lo = moc_f32_to_bf16_rne(r1 - moc_bf16_to_f32(mid));
+    }
+}
+
+template <bool F16, typename V>
+__device__ __forceinline__ f32x4_t moc_mfma_half(const V& a, const V& b, f32x4_t c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
 // Exclusive prefix over a block of 0/1 flags.  `wave_tot` is LDS scratch with one

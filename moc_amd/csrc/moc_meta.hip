@@ -72,33 +72,40 @@ struct FwdArgs {
 //   bf16 bags: [nt][kk][term][lane][8] bf16, element j of lane l = term t of W1[nt*16 + (l&15)][kk*32 + (l>>4)*8 + j]
 //              (hi/mid/lo split, 24 mantissa bits: bf16 MFMA with fp32-exact products)
 //   fp32 bags: [nt][kq][lane][4] f32,         element m of lane l = W1[nt*16 + (l&15)][kq*16 + (l>>4)*4 + m]
-__device__ __forceinline__ void w1_image_store_bf16(unsigned char* img, int D, int h, int d, float w) {
+//   fp16 bags: as bf16, the three fp16 terms of W1 * 2^10 (moc_common.h); the forward scales back
+template <bool F16>
+__device__ __forceinline__ void w1_image_store_half(unsigned char* img, int D, int h, int d, float w) {
     const int KK = D / 32;
     const int nt = h >> 4, kk = d >> 5, lane = (((d & 31) >> 3) << 4) | (h & 15), j = d & 7;
     uint16_t* o = reinterpret_cast<uint16_t*>(img) + ((size_t)(nt * KK + kk) * 3 * 64 + lane) * 8 + j;
-    const uint16_t hi = moc_f32_to_bf16_rne(w);
-    const float r1 = w - moc_bf16_to_f32(hi);
-    const uint16_t mid = moc_f32_to_bf16_rne(r1);
-    const uint16_t lo = moc_f32_to_bf16_rne(r1 - moc_bf16_to_f32(mid));
+    uint16_t hi, mid, lo;
+    moc_split3<F16>(w, MOC_F16_W1_SCALE, hi, mid, lo);
     o[0] = hi;
     o[64 * 8] = mid;
     o[2 * 64 * 8] = lo;
+}
+__device__ __forceinline__ void w1_image_store_bf16(unsigned char* img, int D, int h, int d, float w) {
+    w1_image_store_half<false>(img, D, h, d, w);
 }
 __device__ __forceinline__ void w1_image_store_f32(unsigned char* img, int D, int h, int d, float w) {
     const int KQ = D / 16;
     const int nt = h >> 4, kq = d >> 4, lane = (((d & 15) >> 2) << 4) | (h & 15), m = d & 3;
     reinterpret_cast<float*>(img)[((size_t)(nt * KQ + kq) * 64 + lane) * 4 + m] = w;
 }
-template <bool BF16>
-__global__ __launch_bounds__(256) void w1_image_kernel(const float* W1, int D, unsigned char* img) {
+// storage code (MOC_F32 / MOC_BF16 / MOC_F16) known at run time
+__device__ __forceinline__ void w1_image_store(int dt, unsigned char* img, int D, int h, int d, float w) {
+    if (dt == MOC_F16) w1_image_store_half<true>(img, D, h, d, w);
+    else if (dt == MOC_BF16) w1_image_store_half<false>(img, D, h, d, w);
+    else w1_image_store_f32(img, D, h, d, w);
+}
+__global__ __launch_bounds__(256) void w1_image_kernel(const float* W1, int D, unsigned char* img, int dt) {
     const int e = blockIdx.x * 256 + threadIdx.x;       // grid = H*D/256
     const int h = e / D, d = e - h * D;
-    if constexpr (BF16) w1_image_store_bf16(img, D, h, d, W1[e]);
-    else w1_image_store_f32(img, D, h, d, W1[e]);
+    w1_image_store(dt, img, D, h, d, W1[e]);
 }
 
 // grid (ceil(S_bound/16), n): one workgroup = 16 selected rows, wave w = hidden units 16w..16w+15.
-template <bool BF16>
+template <bool BF16, bool F16 = false>
 __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
     __shared__ __attribute__((aligned(16))) uint4 xt[16 * 64];     // 16 rows x 1 KiB, chunk-swizzled
     __shared__ float Hs[16][H + 1];
@@ -166,10 +173,9 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
             for (int kk = 0; kk < 16; ++kk) {
                 if (kk < ksteps) {
                     const int r = lane & 15;
-                    const bf16x8_t A = __builtin_bit_cast(bf16x8_t, xt[r * 64 + ((kk * 4 + (lane >> 4)) ^ r)]);
+                    const uint4 A = xt[r * 64 + ((kk * 4 + (lane >> 4)) ^ r)];
 #pragma unroll
-                    for (int t = 0; t < 3; ++t)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, __builtin_bit_cast(bf16x8_t, wv[kk * 3 + t]), acc, 0, 0, 0);
+                    for (int t = 0; t < 3; ++t) acc = moc_mfma_half<F16>(A, wv[kk * 3 + t], acc);
                 }
             }
         } else {
@@ -202,7 +208,10 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
     {   // acc[i] = pre-activation of row (lane>>4)*4+i, hidden unit wave*16 + (lane&15)
         const int hcol = wave * 16 + (lane & 15);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Hs[(lane >> 4) * 4 + i][hcol] = fmaxf(__fadd_rn(acc[i], bias), 0.f);
+        for (int i = 0; i < 4; ++i) {
+            const float pre = F16 ? acc[i] * (1.f / MOC_F16_W1_SCALE) : acc[i];     // exact power-of-two scaling
+            Hs[(lane >> 4) * 4 + i][hcol] = fmaxf(__fadd_rn(pre, bias), 0.f);
+        }
         W2s[threadIdx.x] = w2_pre;
     }
     __syncthreads();
@@ -281,7 +290,7 @@ struct FinishArgs {
     int32_t* n_pair;
     int64_t stride;
     int64_t base_host;              // >= 0: first slot of the (single) slide; seg_host its slot count
-    int seg_host, D, bf16;
+    int seg_host, D, xdt;     // xdt: storage code of X (MOC_F32 / MOC_BF16 / MOC_F16)
     int C, K, slide0, train, apply_adam;
     uint32_t use_bits;
     AdamCoef adam;
@@ -751,7 +760,7 @@ struct FusedArgs {
     float *W1, *m_W1, *v_W1, *g_W1;
     unsigned char* W1img;
     float* W2out;
-    int img_bf16;
+    int img_dt;
     P2pArgs x;              // world > 1: sum the gradient over the node's ranks before the update
 };
 
@@ -831,7 +840,11 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
             const int p = e / vpr, v = e - p * vpr;
             const int64_t row = a.sel_row[base + sidx_s[p]];
             float4 o;
-            if (a.bf16) {
+            if (a.xdt == MOC_F16) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(a.X + (row * D + v * 4) * 2);
+                o.x = moc_f16_to_f32((uint16_t)raw.x); o.y = moc_f16_to_f32((uint16_t)(raw.x >> 16));
+                o.z = moc_f16_to_f32((uint16_t)raw.y); o.w = moc_f16_to_f32((uint16_t)(raw.y >> 16));
+            } else if (a.xdt == MOC_BF16) {
                 const uint2 raw = *reinterpret_cast<const uint2*>(a.X + (row * D + v * 4) * 2);
                 o.x = __uint_as_float(raw.x << 16); o.y = __uint_as_float(raw.x & 0xFFFF0000u);
                 o.z = __uint_as_float(raw.y << 16); o.w = __uint_as_float(raw.y & 0xFFFF0000u);
@@ -936,8 +949,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
                     const int e = (ha + j) * D + d;
                     adam_update(pw[j][sw], pm[j][sw], pv[j][sw], gr[sw][j] * gs, a.adam);
                     g.W1[e] = pw[j][sw]; g.m_W1[e] = pm[j][sw]; g.v_W1[e] = pv[j][sw];
-                    if (g.img_bf16) w1_image_store_bf16(g.W1img, D, ha + j, d, pw[j][sw]);
-                    else w1_image_store_f32(g.W1img, D, ha + j, d, pw[j][sw]);
+                    w1_image_store(g.img_dt, g.W1img, D, ha + j, d, pw[j][sw]);
                 }
             }
         }
@@ -971,7 +983,7 @@ struct W1Args {
 // elements, via LDS) -- with `P_static` >= 0 (the fused step pads its pair list to C*K entries with
 // zero dh) not even n_pair has to arrive first.
 constexpr int W1_MAXP = 64;
-template <bool BF16>
+template <bool BF16, bool F16 = false>
 __global__ __launch_bounds__(256) void w1_update_kernel(W1Args a) {
     __shared__ __attribute__((aligned(16))) float xs[W1_MAXP][256];
     __shared__ float dh_s[W1_MAXP][8];
@@ -1010,10 +1022,10 @@ __global__ __launch_bounds__(256) void w1_update_kernel(W1Args a) {
                     if constexpr (BF16) {
                         const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.X) + row * a.D + col);
                         float4 lo, hi;
-                        lo.x = __uint_as_float(raw.x << 16); lo.y = __uint_as_float(raw.x & 0xFFFF0000u);
-                        lo.z = __uint_as_float(raw.y << 16); lo.w = __uint_as_float(raw.y & 0xFFFF0000u);
-                        hi.x = __uint_as_float(raw.z << 16); hi.y = __uint_as_float(raw.z & 0xFFFF0000u);
-                        hi.z = __uint_as_float(raw.w << 16); hi.w = __uint_as_float(raw.w & 0xFFFF0000u);
+                        lo.x = moc_half_to_f32<F16>((uint16_t)raw.x); lo.y = moc_half_to_f32<F16>((uint16_t)(raw.x >> 16));
+                        lo.z = moc_half_to_f32<F16>((uint16_t)raw.y); lo.w = moc_half_to_f32<F16>((uint16_t)(raw.y >> 16));
+                        hi.x = moc_half_to_f32<F16>((uint16_t)raw.z); hi.y = moc_half_to_f32<F16>((uint16_t)(raw.z >> 16));
+                        hi.z = moc_half_to_f32<F16>((uint16_t)raw.w); hi.w = moc_half_to_f32<F16>((uint16_t)(raw.w >> 16));
                         reinterpret_cast<float4*>(dst)[0] = lo;
                         reinterpret_cast<float4*>(dst)[1] = hi;
                     } else {
@@ -1038,7 +1050,8 @@ __global__ __launch_bounds__(256) void w1_update_kernel(W1Args a) {
             adam_update(pw[j], pm[j], pv[j], g[j] * a.adam.grad_scale, a.adam);
             a.W1[e] = pw[j]; a.m_W1[e] = pm[j]; a.v_W1[e] = pv[j];
             if (a.W1img) {
-                if constexpr (BF16) w1_image_store_bf16(a.W1img, a.D, h0 + j, d, pw[j]);
+                if constexpr (F16) w1_image_store_half<true>(a.W1img, a.D, h0 + j, d, pw[j]);
+                else if constexpr (BF16) w1_image_store_half<false>(a.W1img, a.D, h0 + j, d, pw[j]);
                 else w1_image_store_f32(a.W1img, a.D, h0 + j, d, pw[j]);
             }
         } else a.g_W1[e] = g[j];
@@ -1048,7 +1061,7 @@ __global__ __launch_bounds__(256) void w1_update_kernel(W1Args a) {
 
 // gradients already in g_* (e.g. after an all-reduce): plain Adam over all four tensors
 // (+ the W1 image when `img` is given, so that the next forward needs no rebuild)
-__global__ __launch_bounds__(256) void adam_all_kernel(moc_meta_t M, int D, AdamCoef k, unsigned char* img, int img_bf16) {
+__global__ __launch_bounds__(256) void adam_all_kernel(moc_meta_t M, int D, AdamCoef k, unsigned char* img, int img_dt) {
     const int nW1 = H * D, n = nW1 + H + 4 * H + 4;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
@@ -1060,8 +1073,7 @@ __global__ __launch_bounds__(256) void adam_all_kernel(moc_meta_t M, int D, Adam
     else { o -= 4 * H; p = M.b2; m = M.m_b2; v = M.v_b2; g = M.g_b2; }
     adam_update(p[o], m[o], v[o], g[o] * k.grad_scale, k);
     if (img && e < nW1) {
-        if (img_bf16) w1_image_store_bf16(img, D, e / D, e % D, p[o]);
-        else w1_image_store_f32(img, D, e / D, e % D, p[o]);
+        w1_image_store(img_dt, img, D, e / D, e % D, p[o]);
     }
 }
 
@@ -1101,8 +1113,7 @@ int check_meta(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* w
 int launch_w1_image(const moc_batch_t* B, const moc_meta_t* M, hipStream_t s) {
     MOC_REQUIRE(M->W1_image, "meta: W1_image buffer is null (moc_w1_image_bytes)");
     const int grid = H * B->D / 256;
-    if (B->dtype == MOC_BF16) w1_image_kernel<true><<<grid, 256, 0, s>>>(M->W1, B->D, (unsigned char*)M->W1_image);
-    else w1_image_kernel<false><<<grid, 256, 0, s>>>(M->W1, B->D, (unsigned char*)M->W1_image);
+    w1_image_kernel<<<grid, 256, 0, s>>>(M->W1, B->D, (unsigned char*)M->W1_image, B->dtype);
     MOC_CHECK_LAUNCH("moc_w1_image");
     return MOC_OK;
 }
@@ -1122,7 +1133,8 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
     a.D = B->D; a.C = B->C; a.slide0 = slide0; a.use_bits = use_bits;
     a.base_host = (n == 1 && B->row_off_host) ? B->row_off_host[slide0] : -1;
     dim3 grid(moc_cdiv(s_bound(B), 16), n);
-    if (B->dtype == MOC_BF16) meta_forward_kernel<true><<<grid, 256, 0, s>>>(a);
+    if (B->dtype == MOC_F16) meta_forward_kernel<true, true><<<grid, 256, 0, s>>>(a);
+    else if (B->dtype == MOC_BF16) meta_forward_kernel<true><<<grid, 256, 0, s>>>(a);
     else meta_forward_kernel<false><<<grid, 256, 0, s>>>(a);
     MOC_CHECK_LAUNCH("moc_meta_forward");
     return MOC_OK;
@@ -1180,7 +1192,7 @@ int launch_pool_finish(const moc_batch_t* B, const moc_meta_t* M, const moc_meta
     a.pair_dh = ws->pair_dh; a.pair_row = ws->pair_row; a.n_pair = ws->n_pair;
     a.stride = B->total_rows; a.C = B->C; a.K = B->topk; a.slide0 = slide0; a.train = train;
     a.apply_adam = apply_adam; a.use_bits = use_bits; a.adam = k;
-    a.pair_x = ws->pair_x; a.X = (const unsigned char*)B->X; a.D = B->D; a.bf16 = B->dtype == MOC_BF16;
+    a.pair_x = ws->pair_x; a.X = (const unsigned char*)B->X; a.D = B->D; a.xdt = B->dtype;   /* storage code: 0 f32, 1 bf16, 2 f16 */
     a.base_host = -1; a.seg_host = 0;
     if (n == 1 && B->row_off_host) {
         a.base_host = B->row_off_host[slide0];
@@ -1227,14 +1239,14 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
     a.stride = B->total_rows; a.C = B->C; a.K = B->topk; a.slide0 = slide; a.train = 1;
     a.apply_adam = apply_adam; a.use_bits = use_bits; a.adam = k;
     a.g_W2 = M->g_W2; a.g_b2 = M->g_b2; a.g_b1 = M->g_b1; g.g_W1 = M->g_W1;
-    a.X = (const unsigned char*)B->X; a.D = B->D; a.bf16 = B->dtype == MOC_BF16;
+    a.X = (const unsigned char*)B->X; a.D = B->D; a.xdt = B->dtype;   /* storage code: 0 f32, 1 bf16, 2 f16 */
     a.base_host = -1; a.seg_host = 0;
     if (B->row_off_host) {
         a.base_host = B->row_off_host[slide];
         a.seg_host = (int)(B->row_off_host[slide + 1] - a.base_host);
     }
     g.W1 = M->W1; g.m_W1 = M->m_W1; g.v_W1 = M->v_W1; g.W1img = (unsigned char*)M->W1_image;
-    g.W2out = W2out; g.img_bf16 = B->dtype == MOC_BF16;
+    g.W2out = W2out; g.img_dt = B->dtype;
     const int cap = B->C <= 8 ? PS_CAP_MAX : PS_CAP_MAX / 2;
     const size_t smem = fused_step_smem(B, cap);
     static bool attr_set = false;
@@ -1258,7 +1270,8 @@ int launch_w1(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws
     a.X = (const unsigned char*)B->X; a.pair_dh = ws->pair_dh; a.pair_row = ws->pair_row; a.n_pair = ws->n_pair;
     a.W1 = M->W1; a.m_W1 = M->m_W1; a.v_W1 = M->v_W1; a.g_W1 = M->g_W1; a.D = B->D; a.apply_adam = apply_adam; a.adam = k;
     const dim3 grid(B->D / 256, H / 8);
-    if (B->dtype == MOC_BF16) w1_update_kernel<true><<<grid, 256, 0, s>>>(a);
+    if (B->dtype == MOC_F16) w1_update_kernel<true, true><<<grid, 256, 0, s>>>(a);
+    else if (B->dtype == MOC_BF16) w1_update_kernel<true><<<grid, 256, 0, s>>>(a);
     else w1_update_kernel<false><<<grid, 256, 0, s>>>(a);
     MOC_CHECK_LAUNCH("moc_w1_update");
     return MOC_OK;
@@ -1358,7 +1371,7 @@ extern "C" int moc_train_steps_dp(const moc_batch_t* B, const moc_meta_t* M, con
     hipStream_t s = (hipStream_t)stream;
     if (int rc = launch_w1_image(B, M, s)) return rc;      // afterwards the Adam kernel keeps it in sync
     const bool fused = fused_step_ok(B, ws);
-    const int img_bf16 = B->dtype == MOC_BF16;
+    const int img_dt = B->dtype;
     AdamCoef kg = {};
     kg.grad_scale = 1.f;
     for (int t = 0; t < n; ++t) {
@@ -1375,7 +1388,7 @@ extern "C" int moc_train_steps_dp(const moc_batch_t* B, const moc_meta_t* M, con
             if (rc != 0) MOC_FAIL(MOC_ELAUNCH, "moc_train_steps_dp: all-reduce failed at step %d (rc=%d)", t, rc);
         }
         const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f / (float)world);
-        adam_all_kernel<<<moc_cdiv(n_par, 256), 256, 0, s>>>(*M, M->D, k, (unsigned char*)M->W1_image, img_bf16);
+        adam_all_kernel<<<moc_cdiv(n_par, 256), 256, 0, s>>>(*M, M->D, k, (unsigned char*)M->W1_image, img_dt);
         MOC_CHECK_LAUNCH("moc_train_steps_dp");
     }
     return MOC_OK;
@@ -1464,5 +1477,5 @@ extern "C" int moc_train_steps(const moc_batch_t* B, const moc_meta_t* M, const 
 
 extern "C" size_t moc_w1_image_bytes(int D, int dtype) {
     if (D <= 0) return 0;
-    return dtype == MOC_BF16 ? (size_t)D * H * 3 * 2 : (size_t)D * H * 4;
+    return dtype != MOC_F32 ? (size_t)D * H * 3 * 2 : (size_t)D * H * 4;
 }

@@ -34,8 +34,16 @@ __device__ __forceinline__ float bank_elem(const float* W, const float* We, int 
     return We[(int64_t)k * Ce + n];
 }
 
-// bf16 image: [nt][kk][term][lane][8] bf16, element j of lane l = Wcat[kk*32 + (l>>4)*8 + j][nt*16 + (l&15)]
-__global__ void prepare_bank_bf16_kernel(const float* W, const float* We, int D, int C, int Ce,
+// |w| of every bank element < 2 ?  (fp16 image only: w * 2^14 must stay inside fp16)
+__global__ void bank_range_kernel(const float* W, int64_t nW, const float* We, int64_t nWe, int* bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nW && !(fabsf(W[i]) < 2.f)) atomicOr(bad, 1);
+    if (i < nWe && !(fabsf(We[i]) < 2.f)) atomicOr(bad, 1);
+}
+
+// 16-bit image: [nt][kk][term][lane][8] bf16 / fp16, element j of lane l = Wcat[kk*32 + (l>>4)*8 + j][nt*16 + (l&15)]
+template <bool F16>
+__global__ void prepare_bank_half_kernel(const float* W, const float* We, int D, int C, int Ce,
                                          int fg_from_ext, uint16_t* out) {
     const int KK = D / 32, NT = (Ce + 15) / 16;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,11 +54,8 @@ __global__ void prepare_bank_bf16_kernel(const float* W, const float* We, int D,
     for (int j = 0; j < 8; ++j) {
         const int k = kk * 32 + (lane >> 4) * 8 + j;
         const float w = bank_elem(W, We, C, Ce, fg_from_ext, k, n);
-        const uint16_t hi = moc_f32_to_bf16_rne(w);
-        const float r1 = w - moc_bf16_to_f32(hi);
-        const uint16_t mid = moc_f32_to_bf16_rne(r1);
-        const float r2 = r1 - moc_bf16_to_f32(mid);
-        const uint16_t lo = moc_f32_to_bf16_rne(r2);
+        uint16_t hi, mid, lo;
+        moc_split3<F16>(w, MOC_F16_BANK_SCALE, hi, mid, lo);
         o[j] = hi;
         o[64 * 8 + j] = mid;
         o[2 * 64 * 8 + j] = lo;
@@ -102,6 +107,7 @@ struct ScoresArgs {
     int64_t stride;          // total_rows
     int D, C, Ce, NT;
     int tpw;                 // 16-row tiles per wave (1 when NT > 1)
+    float oscale;            // products -> logits: 1, or 2^-14 for the scaled fp16 image
 };
 
 // one lane per row: reads the 16 x Ctp tile the wave just wrote, emits the statistics
@@ -188,7 +194,7 @@ __device__ __forceinline__ void row_epilogue_wide(const ScoresArgs& a, const flo
 }
 
 // CH = elements of K held in registers per chunk (512 or 256).  BF16: bf16 bag.
-template <int CH, bool BF16>
+template <int CH, bool BF16, bool F16 = false>
 __global__ __launch_bounds__(256) void scores_kernel(ScoresArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ESZ = BF16 ? 2 : 4;
@@ -236,11 +242,9 @@ __global__ __launch_bounds__(256) void scores_kernel(ScoresArgs a) {
                     const uint4* bp = lds_b + (ch * NFRAG) * 3 * 64 + lane;
 #pragma unroll
                     for (int f = 0; f < NFRAG; ++f) {
-                        const bf16x8_t A = __builtin_bit_cast(bf16x8_t, af[f]);
 #pragma unroll
                         for (int term = 0; term < 3; ++term) {
-                            const bf16x8_t Bv = __builtin_bit_cast(bf16x8_t, bp[(f * 3 + term) * 64]);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bv, acc, 0, 0, 0);
+                            acc = moc_mfma_half<F16>(af[f], bp[(f * 3 + term) * 64], acc);
                         }
                     }
                 } else {
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void scores_kernel(ScoresArgs a) {
             // C/D layout: acc[i] = out[row (lane>>4)*4 + i][col lane&15]
             wave_lds_sync();   // previous epilogue reads of this tile are done
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tile[((lane >> 4) * 4 + i) * ldt + nt * 16 + (lane & 15)] = acc[i];
+            for (int i = 0; i < 4; ++i) tile[((lane >> 4) * 4 + i) * ldt + nt * 16 + (lane & 15)] = acc[i] * a.oscale;
             wave_lds_sync();
             if (nt == a.NT - 1 && lane < 16)
                 row_epilogue(a, tile + lane * ldt, ldt, base, row0 + lane, row0 + lane < nk);
@@ -356,7 +360,7 @@ __device__ __forceinline__ void compute_pairs_impl(const u32x4_t (&buf)[NF], u32
 // bank image (NT x img) resident in LDS: NT > 1 leaves room for one workgroup per CU only.
 // The launch covers slides [slide0, slide0 + n_slides) (the launcher chunks a batch whose per-slide
 // metadata would not fit beside the image).
-template <int NF, bool BF16, int NT>
+template <int NF, bool BF16, int NT, bool F16 = false>
 __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(ScoresArgs a, int slide0, int n_slides) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ESZ = BF16 ? 2 : 4;
@@ -465,9 +469,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
                 for (int term = 0; term < 3; ++term)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)            // independent accumulators back to back
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, A),
-                                                                          __builtin_bit_cast(bf16x8_t, Bv[term * NT + nt]),
-                                                                          acc[nt], 0, 0, 0);
+                        acc[nt] = moc_mfma_half<F16>(A, Bv[term * NT + nt], acc[nt]);
             } else {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) tile[((lane >> 4) * 4 + i) * LDT + nt * 16 + (lane & 15)] = acc[nt][i];
+                for (int i = 0; i < 4; ++i) tile[((lane >> 4) * 4 + i) * LDT + nt * 16 + (lane & 15)] = acc[nt][i] * a.oscale;
             wave_lds_order();
             row_epilogue_wide<NT>(a, tile, u.base, u.row0, u.nk);
 #pragma unroll
@@ -695,21 +697,38 @@ static int bank_nt(int Ce) { return (Ce + 15) / 16; }
 
 extern "C" size_t moc_bank_bytes(int D, int Ce, int dtype) {
     if (D <= 0 || Ce <= 0) return 0;
-    const size_t per_nt = dtype == MOC_BF16 ? (size_t)(D / 32) * 3 * 1024 : (size_t)(D / 16) * 1024;
+    const size_t per_nt = dtype != MOC_F32 ? (size_t)(D / 32) * 3 * 1024 : (size_t)(D / 16) * 1024;
     return per_nt * bank_nt(Ce);
 }
 
 extern "C" int moc_prepare_bank(const float* W, const float* W_ext, int D, int C, int Ce, int dtype,
                                 int fg_from_ext, void* bank_out, moc_stream_t stream) {
     MOC_REQUIRE(W && W_ext && bank_out, "moc_prepare_bank: null pointer");
-    MOC_REQUIRE(dtype == MOC_F32 || dtype == MOC_BF16, "moc_prepare_bank: bad dtype %d", dtype);
+    MOC_REQUIRE(dtype == MOC_F32 || dtype == MOC_BF16 || dtype == MOC_F16, "moc_prepare_bank: bad dtype %d", dtype);
     MOC_REQUIRE(C >= 2 && Ce > C, "moc_prepare_bank: need 2 <= C < Ce (logits should have more bg classes), got C=%d Ce=%d", C, Ce);
     MOC_REQUIRE(D > 0 && D % 256 == 0, "moc_prepare_bank: D=%d must be a multiple of 256", D);
     hipStream_t s = (hipStream_t)stream;
     const int NT = bank_nt(Ce);
-    if (dtype == MOC_BF16) {
+    if (dtype == MOC_F16) {
+        // the fp16 image holds w * 2^14: every |w| must be < 2 (cosine classifiers are unit-norm columns).
+        // Checked here, once per bank, with a host round trip.
+        int* bad = nullptr;
+        int host_bad = 0;
+        if (hipMalloc((void**)&bad, sizeof(int)) != hipSuccess) MOC_FAIL(MOC_ELAUNCH, "moc_prepare_bank: hipMalloc failed");
+        (void)hipMemsetAsync(bad, 0, sizeof(int), s);
+        const int64_t nW = (int64_t)D * C, nWe = (int64_t)D * Ce;
+        bank_range_kernel<<<moc_cdiv(nWe, 256), 256, 0, s>>>(W, nW, W_ext, nWe, bad);
+        const hipError_t e = hipMemcpyAsync(&host_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(bad);
+        if (e != hipSuccess) MOC_FAIL(MOC_ELAUNCH, "moc_prepare_bank: range check failed: %s", hipGetErrorString(e));
+        MOC_REQUIRE(!host_bad, "moc_prepare_bank: fp16 bags need classifier weights with |w| < 2 (unit-norm columns); "
+                    "use bf16 or fp32 storage for this bank");
         const int total = NT * (D / 32) * 64;
-        prepare_bank_bf16_kernel<<<moc_cdiv(total, 256), 256, 0, s>>>(W, W_ext, D, C, Ce, fg_from_ext, (uint16_t*)bank_out);
+        prepare_bank_half_kernel<true><<<moc_cdiv(total, 256), 256, 0, s>>>(W, W_ext, D, C, Ce, fg_from_ext, (uint16_t*)bank_out);
+    } else if (dtype == MOC_BF16) {
+        const int total = NT * (D / 32) * 64;
+        prepare_bank_half_kernel<false><<<moc_cdiv(total, 256), 256, 0, s>>>(W, W_ext, D, C, Ce, fg_from_ext, (uint16_t*)bank_out);
     } else {
         const int total = NT * (D / 16) * 64;
         prepare_bank_f32_kernel<<<moc_cdiv(total, 256), 256, 0, s>>>(W, W_ext, D, C, Ce, fg_from_ext, (float*)bank_out);
@@ -721,7 +740,7 @@ extern "C" int moc_prepare_bank(const float* W, const float* W_ext, int D, int C
 int moc_check_batch(const moc_batch_t* B, const char* who) {
     MOC_REQUIRE(B, "%s: null batch", who);
     MOC_REQUIRE(B->X && B->row_off, "%s: null X/row_off", who);
-    MOC_REQUIRE(B->dtype == MOC_F32 || B->dtype == MOC_BF16, "%s: bad dtype %d", who, B->dtype);
+    MOC_REQUIRE(B->dtype == MOC_F32 || B->dtype == MOC_BF16 || B->dtype == MOC_F16, "%s: bad dtype %d", who, B->dtype);
     MOC_REQUIRE(B->D > 0 && B->D % 256 == 0, "%s: D=%d must be a multiple of 256", who, B->D);
     MOC_REQUIRE(((uintptr_t)B->X & 15) == 0, "%s: X must be 16-byte aligned", who);
     MOC_REQUIRE(B->n_slides > 0 && B->total_rows > 0 && B->max_rows > 0 && B->max_rows <= B->total_rows,
@@ -755,7 +774,9 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
     a.sel_flag = B->sel_flag;
     a.stride = B->total_rows;
     a.D = B->D; a.C = B->C; a.Ce = B->Ce; a.NT = bank_nt(B->Ce);
-    const bool bf = B->dtype == MOC_BF16;
+    const bool bf = B->dtype != MOC_F32;          // 16-bit storage (bf16 or fp16): 3-term image, K = 32 per MFMA
+    const bool f16 = B->dtype == MOC_F16;
+    a.oscale = f16 ? 1.f / MOC_F16_BANK_SCALE : 1.f;
     const size_t img = bf ? (size_t)(B->D / 32) * 3 * 1024 : (size_t)(B->D / 16) * 1024;
     hipStream_t s = (hipStream_t)stream;
     // streaming form: persistent workgroups over the flat tile list, the whole bank image (all NT
@@ -783,7 +804,7 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
         // rows of exactly one KiB unit only: with two units per row the two 32-register tile buffers no
         // longer fit beside the bank image, hipcc parks in-flight load destinations in AGPRs and the
         // data arriving later lands in registers that have been re-used (tests/test_isa_hazards_cpu.py)
-        const bool rows_ok = row_b == 1024 && a.NT == 1;
+        const bool rows_ok = row_b == 1024 && a.NT == 1 && !f16;
         if (rows_ok && variant && variant[0] == 'r') {
             const size_t smem2 = 4 * 16 * 1024 + 4 * 16 * 17 * sizeof(float) + (size_t)B->n_slides * 24 + 16;
             MOC_REQUIRE(smem2 <= 160 * 1024, "moc_scores: n_slides=%d needs %zu B of LDS (> 160 KiB)", B->n_slides, smem2);
@@ -804,28 +825,32 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
             MOC_CHECK_LAUNCH("moc_scores(rows)");
             return MOC_OK;
         }
-#define MOC_LAUNCH_STREAM(NF, BF, NTT)                                                                  \
+#define MOC_LAUNCH_STREAM(NF, BF, NTT, FH)                                                              \
         do {                                                                                            \
             static bool attr_set = false;                                                               \
             if (!attr_set) {                                                                            \
-                (void)hipFuncSetAttribute((const void*)scores_stream_kernel<NF, BF, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                (void)hipFuncSetAttribute((const void*)scores_stream_kernel<NF, BF, NTT, FH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                 attr_set = true;                                                                        \
             }                                                                                           \
-            scores_stream_kernel<NF, BF, NTT><<<wgs, 256, smem, s>>>(a, s0, ns);                        \
+            scores_stream_kernel<NF, BF, NTT, FH><<<wgs, 256, smem, s>>>(a, s0, ns);                    \
         } while (0)
-#define MOC_LAUNCH_STREAM_NT(NF, BF)                                                                    \
+#define MOC_LAUNCH_STREAM_NT(NF, BF, FH)                                                                \
         do {                                                                                            \
-            if (a.NT == 1) MOC_LAUNCH_STREAM(NF, BF, 1);                                                \
-            else if (a.NT == 2) MOC_LAUNCH_STREAM(NF, BF, 2);                                           \
-            else if (a.NT == 3) MOC_LAUNCH_STREAM(NF, BF, 3);                                           \
-            else if constexpr (!BF) MOC_LAUNCH_STREAM(NF, BF, 4);                                       \
+            if (a.NT == 1) MOC_LAUNCH_STREAM(NF, BF, 1, FH);                                            \
+            else if (a.NT == 2) MOC_LAUNCH_STREAM(NF, BF, 2, FH);                                       \
+            else if (a.NT == 3) MOC_LAUNCH_STREAM(NF, BF, 3, FH);                                       \
+            else if constexpr (!BF) MOC_LAUNCH_STREAM(NF, BF, 4, FH);                                   \
         } while (0)
         for (int s0 = 0; s0 < B->n_slides; s0 += chunk) {
             const int ns = B->n_slides - s0 < chunk ? B->n_slides - s0 : chunk;
             if (row_b % 1024 == 0) {
-                if (bf) MOC_LAUNCH_STREAM_NT(16, true); else MOC_LAUNCH_STREAM_NT(16, false);
+                if (f16) MOC_LAUNCH_STREAM_NT(16, true, true);
+                else if (bf) MOC_LAUNCH_STREAM_NT(16, true, false);
+                else MOC_LAUNCH_STREAM_NT(16, false, false);
             } else {
-                if (bf) MOC_LAUNCH_STREAM_NT(8, true); else MOC_LAUNCH_STREAM_NT(8, false);
+                if (f16) MOC_LAUNCH_STREAM_NT(8, true, true);
+                else if (bf) MOC_LAUNCH_STREAM_NT(8, true, false);
+                else MOC_LAUNCH_STREAM_NT(8, false, false);
             }
             MOC_CHECK_LAUNCH("moc_scores(stream)");
         }
@@ -837,19 +862,23 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
     const size_t smem = img + (size_t)4 * 16 * (a.NT * 16 + 1) * sizeof(float);
     MOC_REQUIRE(smem <= 160 * 1024, "moc_scores: D=%d needs %zu B of LDS (> 160 KiB)", B->D, smem);
     dim3 grid(moc_cdiv(B->max_rows, 64 * a.tpw), B->n_slides), block(256);
-#define MOC_LAUNCH_SCORES(CH, BF)                                                                       \
+#define MOC_LAUNCH_SCORES(CH, BF, FH)                                                                   \
     do {                                                                                                \
         static bool attr_set = false;                                                                   \
         if (!attr_set) {                                                                                \
-            (void)hipFuncSetAttribute((const void*)scores_kernel<CH, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void*)scores_kernel<CH, BF, FH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                            \
         }                                                                                               \
-        scores_kernel<CH, BF><<<grid, block, smem, s>>>(a);                                             \
+        scores_kernel<CH, BF, FH><<<grid, block, smem, s>>>(a);                                         \
     } while (0)
     if (B->D % 512 == 0) {
-        if (bf) MOC_LAUNCH_SCORES(512, true); else MOC_LAUNCH_SCORES(512, false);
+        if (f16) MOC_LAUNCH_SCORES(512, true, true);
+        else if (bf) MOC_LAUNCH_SCORES(512, true, false);
+        else MOC_LAUNCH_SCORES(512, false, false);
     } else {
-        if (bf) MOC_LAUNCH_SCORES(256, true); else MOC_LAUNCH_SCORES(256, false);
+        if (f16) MOC_LAUNCH_SCORES(256, true, true);
+        else if (bf) MOC_LAUNCH_SCORES(256, true, false);
+        else MOC_LAUNCH_SCORES(256, false, false);
     }
 #undef MOC_LAUNCH_SCORES
     MOC_CHECK_LAUNCH("moc_scores");

@@ -29,7 +29,9 @@ def _dtype_code(dt: torch.dtype) -> int:
         return _lib.MOC_F32
     if dt == torch.bfloat16:
         return _lib.MOC_BF16
-    raise AssertionError(f"bag dtype {dt} unsupported (float32 or bfloat16)")
+    if dt == torch.float16:
+        return _lib.MOC_F16
+    raise AssertionError(f"bag dtype {dt} unsupported (float32, bfloat16 or float16)")
 
 
 class Bank:

@@ -71,7 +71,7 @@ def _bag_dtype(args, default):
     if want in (None, "keep"):
         return default
     return {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
-            "bfloat16": torch.bfloat16}[want]
+            "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16}[want]
 
 
 def _pack(bags, device, dtype):
@@ -177,7 +177,7 @@ def _collect(loader, device, args):
         feats, lbl, coords, full_path = data
         bags.append(feats.squeeze(0))
         labels.append(int(lbl.reshape(-1)[0]))
-    dtype = _bag_dtype(args, bags[0].dtype if bags[0].dtype in (torch.float32, torch.bfloat16) else torch.float32)
+    dtype = _bag_dtype(args, bags[0].dtype if bags[0].dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32)
     X, sizes = _pack(bags, device, dtype)
     return X, sizes, None, labels
 
@@ -211,7 +211,7 @@ def slide_process(feat, zeroshot_weights, zeroshot_weights_ext,
     if device.type != "cuda":
         raise RuntimeError("moc_amd.slide_process: the classifier bank must live on the GPU (no CPU fallback)")
     feat = feat.to(device)
-    if feat.dtype not in (torch.float32, torch.bfloat16):
+    if feat.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         feat = feat.to(torch.float32)
     feat = feat.contiguous()
     N = feat.size(0)

@@ -11,7 +11,7 @@ Same flags and defaults as the reference, same result files (`zs_results_*`, `be
 additive: the dataset branch is table driven (ebrains12 / ebrains30 work like nsclc / rcc); the
 CONCH text tower is not part of this path, so the zero-shot weights must already be cached under
 `models/classifier_weights/` (the reference caches them there on first run, main_moc.py:149-197);
-`--bag_dtype bf16` stores bags as bfloat16; `--resident 0` falls back to per-epoch re-reads;
+`--bag_dtype bf16|fp16` stores bags as bfloat16 / float16; `--resident 0` falls back to per-epoch re-reads;
 `--synthetic N` runs the whole loop on N generated slides per split.
 """
 from __future__ import annotations
@@ -59,7 +59,7 @@ def get_args(argv=None):
     p.add_argument("--summary_dir", type=str, default="")
     # additive
     p.add_argument("--root", type=str, default=".", help="directory holding dataset_csv/, splits/, data/, models/")
-    p.add_argument("--bag_dtype", type=str, default="fp32", choices=["fp32", "bf16"], help="bag storage in HBM")
+    p.add_argument("--bag_dtype", type=str, default="fp32", choices=["fp32", "bf16", "fp16"], help="bag storage in HBM")
     p.add_argument("--resident", type=int, default=1, help="keep each split packed in HBM across epochs")
     p.add_argument("--epochs", type=int, default=25, help="main_moc.py:611 hard-codes 25")
     p.add_argument("--synthetic", type=int, default=0, help="run on N generated slides per split instead of files")
@@ -140,7 +140,7 @@ def prepare(args, device):
         args.n_classes = C
         W, We = synth.make_bank(1234, 512, C)
         M.set_classifier_bank(W.to(device), We.to(device))
-        dt = torch.bfloat16 if args.bag_dtype == "bf16" else torch.float32
+        dt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.bag_dtype, torch.float32)
         loaders = []
         for s, (base, n, rep) in enumerate(((100, args.shot * C, args.shot * C), (5000, args.synthetic, None), (9000, args.synthetic, None))):
             bags, labels = synth.make_slide_set(base, synth.bag_sizes(base, n, 3000, fixed=False, lo=500, hi=8000), 512, We, C)
@@ -169,7 +169,7 @@ def prepare(args, device):
         sp.load_full_path(True)
         sp.load_from_h5(True)
         if args.resident:
-            loaders.append(to_resident(sp, device, torch.bfloat16 if args.bag_dtype == "bf16" else None))
+            loaders.append(to_resident(sp, device, {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.bag_dtype)))
         else:
             loaders.append(torch.utils.data.DataLoader(sp, batch_size=1, shuffle=False, num_workers=1))
     return loaders

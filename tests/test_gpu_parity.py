@@ -35,7 +35,7 @@ def _engine():
 
 
 # ------------------------------------------------------------------ score pass
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,C,D", [(1, 2, 512), (17, 2, 512), (1000, 3, 512), (4099, 30, 512), (700, 64, 1024), (333, 2, 256),
                                    (2500, 20, 512), (1500, 50, 512), (900, 13, 256), (1100, 30, 1024)])
 def test_scores_and_row_stats_match_oracle(dev, dtype, N, C, D):
@@ -57,7 +57,7 @@ def test_scores_and_row_stats_match_oracle(dev, dtype, N, C, D):
     assert int(batch.sel_flag.sum()) == 0
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_scores_many_slides_wide_bank_is_chunked_consistently(dev, dtype):
     """C = 30 keeps the whole 3-tile bank image in LDS, leaving room for ~160 slides' metadata: a
     400-slide batch goes out in chunks and must give, row for row, what one long slide gives."""
@@ -185,7 +185,7 @@ def test_slide_process_matches_reference_fixtures(dev):
         _check_slide_process(dev, r, x[mask], W, We, int(C), int(j), discard, g[f"c{cid}_selected_index"], cands)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_slide_process_full_size_vs_oracle(dev, dtype):
     """BASELINE config 2 shape: 15k x 512, C=2, topj=400, row mask on."""
     M = _mm()
@@ -487,6 +487,10 @@ def test_full_size_properties(dev):
     (2, 10, 60, 768, torch.bfloat16, [500, 650]),              # 1536-byte rows: the 512-B-unit kernels
     (2, 10, 400, 512, torch.float32, [12, 30, 9]),             # S < K on some slides (mean over S rows)
     (5, 13, 40, 256, torch.float32, [400, 300, 350, 500, 450]),
+    (2, 10, 400, 512, torch.float16, [3000, 2500, 2800, 3300]),  # fp16 storage, the one-launch step
+    (3, 10, 100, 1024, torch.float16, [700, 900, 800]),          # fp16, 2-KiB rows
+    (12, 10, 60, 512, torch.float16, [900, 1000, 800, 950] * 3), # fp16, C*K = 120 pairs: general step kernels, 2-tile bank
+    (30, 10, 50, 512, torch.bfloat16, [700] * 30),               # EBRAINS-30 shape: 3-tile bank, 300 pairs
 ])
 def test_train_and_eval_match_oracle_on_odd_shapes(dev, C, K, j, D, dtype, sizes):
     M = _mm()
