@@ -1,0 +1,42 @@
+"""CPU restatement of the pooling / instance-selection steps the baseline models end in (SURVEY.md
+section 8, row f3) -- TEST INFRASTRUCTURE ONLY, like oracle/moc_oracle.py: nothing under moc_amd/
+imports this file.
+
+  topk_mean_pool  models/model_adapters.py:173-183 (`topj_pooling`: per-class mean of the top-j logits)
+  top_rows        models/model_mil.py:40 (`torch.topk(y_probs[:, 1], top_k)[1]`)
+  top_entry       models/model_mil.py:88-89 (`y_probs.view(1, -1).argmax(1)` -> (row, class))
+
+`patched()` swaps them into moc_amd.model_mil / moc_amd.model_adapters so that the CPU tests can pin the
+rest of those modules (layers, mixing formulas, constructor RNG order, trainer hooks) to the fixtures
+tests/golden/baselines.npz, which tests/golden/make_golden.py produced from the reference's own
+classes.  The -m gpu tests run the same cases through the real HIP pooling.
+"""
+import contextlib
+
+import torch
+
+
+def topk_mean_pool(logits: torch.Tensor, k: int) -> torch.Tensor:
+    j = min(int(k), logits.size(0))
+    return logits.topk(j, 0, True, True)[0].mean(dim=0, keepdim=True)
+
+
+def top_rows(scores: torch.Tensor, k: int = 1) -> torch.Tensor:
+    return torch.topk(scores, int(k), dim=0)[1]
+
+
+def top_entry(probs: torch.Tensor):
+    m = int(probs.reshape(1, -1).argmax(1))
+    return m // probs.size(1), m % probs.size(1)
+
+
+@contextlib.contextmanager
+def patched():
+    import moc_amd.model_adapters as A
+    import moc_amd.model_mil as Mm
+    saved = (A.topk_mean_pool, Mm.top_rows, Mm.top_entry)
+    A.topk_mean_pool, Mm.top_rows, Mm.top_entry = topk_mean_pool, top_rows, top_entry
+    try:
+        yield
+    finally:
+        A.topk_mean_pool, Mm.top_rows, Mm.top_entry = saved

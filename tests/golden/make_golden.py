@@ -391,6 +391,101 @@ def gen_summary():
     save("summary", **out)
 
 
+# ----------------------------------------------------------------------------------------------
+# the baseline models and trainer hooks.  models/model_mil.py imports
+# nystrom_attention, models/model_adapters.py imports openslide and utils/core_utils.py imports every
+# model family -- none importable here -- so the definitions are taken from the AST, as for main_moc.py.
+def _extract(path, names, ns):
+    tree = ast.parse(open(os.path.join(REF, path)).read())
+    body = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    assert {n.name for n in body} == set(names), (path, names)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def load_reference_baselines():
+    from sklearn.metrics import auc as calc_auc
+    from sklearn.metrics import roc_curve
+    from sklearn.preprocessing import label_binarize
+    base = dict(torch=torch, nn=nn, F=F, np=np, os=os)
+    util = _extract("utils/utils.py", ["detect_nan", "calculate_error"], dict(base))
+    mil = _extract("models/model_mil.py", ["initialize_weights", "MIL_fc", "MIL_fc_mc"], dict(base))
+    ada = _extract("models/model_adapters.py",
+                   ["Linear_Adapter", "uncertainty", "Conch_CLIP_Ada", "Conch_TIP_Ada", "load_balancing_loss_func",
+                    "SwitchGate", "Conch_MOE_CLIP_Ada", "Conch_AMUVanilla_Ada", "Conch_AMUTip_Ada"],
+                   dict(base, detect_nan=util["detect_nan"]))
+    class _Np:                       # utils/core_utils.py:71 says `np.Inf`, an alias NumPy 2 dropped: same constant
+        Inf = np.inf
+
+        def __getattr__(self, k):
+            return getattr(np, k)
+    core = _extract("utils/core_utils.py", ["Accuracy_Logger", "EarlyStopping", "train_loop", "validate", "summary"],
+                    dict(base, np=_Np(), calculate_error=util["calculate_error"], roc_auc_score=roc_auc_score, roc_curve=roc_curve,
+                         calc_auc=calc_auc, label_binarize=label_binarize))
+    return mil, ada, core
+
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers_baselines import (BASELINE_CASES, HOOK_CASES, EARLY_SEQS, build_case, run_case, psig as _psig,  # noqa: E402
+                               randn as _randn, hook_bags, Loader)
+
+
+def gen_baselines():
+    mil, ada, core = load_reference_baselines()
+    arrays = {"cases": np.asarray([c[0] for c in BASELINE_CASES])}
+    for i, (name, kind, kw, N, label) in enumerate(BASELINE_CASES):
+        seed = 4000 + 17 * i
+        ns = mil if kind.startswith("MIL") else ada
+        cls, kwargs = build_case(ns, kind, kw, seed)
+        model = cls(**kwargs)
+        arrays[f"{name}:psig"] = _psig(model)
+        for k, v in run_case(model, kind, N, label, seed).items():
+            arrays[f"{name}:{k}"] = v
+    # ---- trainer hooks: one epoch of train_loop, validate with early stopping, summary
+    import contextlib
+    import io
+    import tempfile
+    import pandas as pd
+
+    for tag, kind, kw, d, C in HOOK_CASES:
+        torch.manual_seed(77)
+        model = mil[kind](**kw)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5)
+        tr, va = Loader(hook_bags(6000, 8, d, C)), Loader(hook_bags(6100, 8, d, C))
+        va.dataset = types.SimpleNamespace(slide_data=pd.DataFrame({"slide_id": [f"s{k}" for k in range(len(va))]}))
+        loss_fn = nn.CrossEntropyLoss()
+        with tempfile.TemporaryDirectory() as td, contextlib.redirect_stdout(io.StringIO()):
+            stop = core["EarlyStopping"](patience=2, stop_epoch=1, verbose=True)
+            trace = []
+            for epoch in range(5):
+                core["train_loop"](epoch, model, tr, opt, C, None, loss_fn)
+                fired = core["validate"](0, epoch, model, va, C, stop, None, loss_fn, td)
+                trace.append([float(fired), stop.counter, float(stop.best_score), float(stop.val_loss_min)])
+                if fired:
+                    break
+            res, err, auc, logger = core["summary"](model, va, C)
+        arrays[f"{tag}:psig"] = _psig(model)
+        arrays[f"{tag}:trace"] = np.asarray(trace)
+        arrays[f"{tag}:summary"] = np.asarray([err, auc])
+        arrays[f"{tag}:acc"] = np.asarray([[c if c is not None else -1 for c in (logger.get_summary(i)[1], logger.get_summary(i)[2])] for i in range(C)], dtype=np.float64)
+        arrays[f"{tag}:probs"] = np.stack([res[f"s{k}"]["prob"].reshape(-1) for k in range(len(va))])
+    # ---- EarlyStopping alone, loss-driven and criteria-driven sequences
+    class Dummy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = nn.Parameter(torch.zeros(1))
+    for k, seq in EARLY_SEQS.items():
+        with tempfile.TemporaryDirectory() as td, contextlib.redirect_stdout(io.StringIO()):
+            es = core["EarlyStopping"](patience=2, stop_epoch=3, verbose=True)
+            tr = []
+            for e, l, c in seq:
+                es(e, l, Dummy(), ckpt_name=os.path.join(td, "c.pt"), criteria=c)
+                tr.append([es.counter, float(es.best_score), float(es.early_stop), float(es.val_loss_min)])
+        arrays[f"early:{k}"] = np.asarray(tr)
+        arrays[f"early:{k}:in"] = np.asarray([[e, l, -1.0 if c is None else c] for e, l, c in seq])
+    save("baselines", **arrays)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]          # e.g. `make_golden.py driver` regenerates one fixture
     ref = load_reference_main()
@@ -406,3 +501,4 @@ if __name__ == "__main__":
     gen_eval(ref)
     gen_driver(ref)
     gen_summary()
+    gen_baselines()

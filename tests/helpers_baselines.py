@@ -1,0 +1,149 @@
+"""Shared by tests/golden/make_golden.py (run on the reference's classes) and the baseline tests (run on
+moc_amd's): the case table, how a case is constructed and exercised, and the signatures compared."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from moc_amd import synth
+
+def randn(seed, *shape):
+    return torch.from_numpy(synth._rng(seed).standard_normal(shape).astype(np.float32))
+
+
+def psig(model):
+    """Order-stable signature of the parameters: (sum, abs-sum, weighted sum) per tensor."""
+    out = []
+    for _, p in sorted(model.named_parameters()):
+        v = p.detach().cpu().double().reshape(-1)
+        out.append([float(v.sum()), float(v.abs().sum()), float((v * torch.arange(1, v.numel() + 1, dtype=torch.float64)).sum() / v.numel())])
+    return np.asarray(out)
+
+
+def gsig(model):
+    """Gradients: small tensors whole, big ones as their row / column sums."""
+    out = {}
+    for n, p in sorted(model.named_parameters()):
+        g = torch.zeros_like(p) if p.grad is None else p.grad.detach()
+        if g.numel() <= 4096:
+            out[n] = g.cpu().numpy().copy()
+        else:
+            out[n + ":rows"] = g.sum(1).cpu().numpy().copy()
+            out[n + ":cols"] = g.sum(0).cpu().numpy().copy()
+    return out
+
+
+BASELINE_CASES = [
+    # name, kind, ctor kwargs (classifier/sample tensors are built from seeds in build_case), N, label
+    ("mil_fc", "MIL_fc", dict(size_arg="benchmark"), 300, 1),
+    ("mil_fc_small", "MIL_fc", dict(size_arg="small"), 37, 0),
+    ("mil_mc", "MIL_fc_mc", dict(n_classes=4), 200, 2),
+    ("clip", "Conch_CLIP_Ada", dict(num_classes=3, topj=10), 400, 1),
+    ("clip_short", "Conch_CLIP_Ada", dict(num_classes=2, topj=10), 6, 0),          # N < topj
+    ("tip", "Conch_TIP_Ada", dict(num_classes=3), 350, 2),
+    ("tip_cache", "Conch_TIP_Ada", dict(num_classes=3, samples=12), 350, 0),
+    ("moe", "Conch_MOE_CLIP_Ada", dict(ada_num=3, topj=8, num_classes=3), 300, 1),
+    ("moe_switch", "Conch_MOE_CLIP_Ada", dict(ada_num=4, topj=10, num_classes=2, use_switch_gate=True, use_balance_loss=True), 300, 1),
+    ("moe_router", "Conch_MOE_CLIP_Ada", dict(ada_num=3, topj=10, num_classes=2, router=True, router_trainable=False), 250, 0),
+    ("amu_none", "Conch_AMUVanilla_Ada", dict(num_classes=3), 300, 1),
+    ("amu_entropy", "Conch_AMUVanilla_Ada", dict(num_classes=3, uncertainty_type="entropy", uncertainty_power=0.5), 300, 1),
+    ("amu_energy", "Conch_AMUVanilla_Ada", dict(num_classes=3, uncertainty_type="energy", uncertainty_power=2.0), 300, 2),
+    ("amu_max", "Conch_AMUVanilla_Ada", dict(num_classes=3, uncertainty_type="max"), 300, 0),
+    ("amu_maxmin", "Conch_AMUVanilla_Ada", dict(num_classes=3, uncertainty_type="max-min"), 300, 0),
+    ("amu_var", "Conch_AMUVanilla_Ada", dict(num_classes=3, uncertainty_type="var"), 300, 0),
+    ("amu_top5", "Conch_AMUVanilla_Ada", dict(num_classes=6, uncertainty_type="top5"), 300, 4),
+    ("amu_moment", "Conch_AMUVanilla_Ada", dict(num_classes=3, uncertainty_type="moment"), 300, 0),
+    ("amutip", "Conch_AMUTip_Ada", dict(num_classes=3, samples=9), 280, 2),
+]
+
+
+def build_case(ns, kind, kw, seed, device="cpu"):
+    """Construct `kind` from namespace `ns` (reference or product) the same way for both sides.
+    Tensors handed to the constructor live on `device`; the module itself is built on the CPU under
+    the seed (same RNG stream on both sides) and moved by the caller."""
+    kw = dict(kw)
+    C = kw.get("num_classes", kw.get("n_classes", 2))
+    if kind.startswith("Conch"):
+        _, We = synth.make_bank(seed, 512, C)
+        kw["classifier_tensor"] = We[:, :C].contiguous().to(device)
+        if kind == "Conch_MOE_CLIP_Ada":
+            kw.pop("num_classes")
+            if kw.pop("router", False):
+                kw["router_tensor"] = (randn(seed + 5, 512, kw["ada_num"]) * 0.05).to(device)
+        ns_samples = kw.pop("samples", None)
+        if ns_samples:
+            lab = [i % C for i in range(ns_samples)]
+            kw["sample_features"] = (randn(seed + 1, ns_samples, 512).to(device), lab)
+            if kind == "Conch_AMUTip_Ada":
+                kw["aux_sample_features"] = (randn(seed + 2, ns_samples, 1024).to(device), lab)
+    torch.manual_seed(seed)
+    return getattr(ns, kind) if not isinstance(ns, dict) else ns[kind], kw
+
+
+def run_case(model, kind, N, label, seed, device="cpu"):
+    """-> dict of outputs and gradient signatures (numpy, host)."""
+    d_in = {"MIL_fc": None, "MIL_fc_mc": 1024}.get(kind, 512)
+    if kind == "MIL_fc":
+        d_in = model.classifier[0].in_features
+    x = randn(seed + 100, N, d_in).to(device)
+    out = {}
+    y = torch.tensor([label], device=device)
+    if kind.startswith("MIL"):
+        top, prob, yhat, yprobs, _ = model(x)
+        out.update(top=top.detach().cpu().numpy(), prob=prob.detach().cpu().numpy(), yhat=yhat.cpu().numpy().reshape(-1),
+                   yprobs=yprobs.detach().cpu().numpy())
+        loss = F.cross_entropy(top, y)
+    elif "AMU" in kind:
+        aux = randn(seed + 200, N, 1024).to(device)
+        res = model(x.clone(), aux.clone())
+        pooled = res[0] if isinstance(res, tuple) else res
+        out["pooled"] = pooled.detach().cpu().numpy()
+        loss = F.cross_entropy(pooled, y)
+        if isinstance(res, tuple):
+            out["pooled_aux"] = res[1].detach().cpu().numpy()
+            loss = loss + 0.5 * F.cross_entropy(res[1], y)
+        out["zero_shot"] = model.forward_disable_ada(x.clone(), aux.clone()).detach().cpu().numpy()
+    else:
+        res = model(x.clone())
+        pooled = res[0] if isinstance(res, tuple) else res
+        out["pooled"] = pooled.detach().cpu().numpy()
+        loss = F.cross_entropy(pooled, y)
+        if isinstance(res, tuple):
+            out["balance"] = np.asarray([float(res[1].detach())])
+            loss = loss + 0.1 * res[1]
+        out["zero_shot"] = model.forward_disable_ada(x.clone()).detach().cpu().numpy()
+    out["loss"] = np.asarray([float(loss.detach())])
+    loss.backward()
+    for k, v in gsig(model).items():
+        out["grad:" + k] = v
+    return out
+
+
+
+HOOK_CASES = (("hooks2", "MIL_fc", dict(size_arg="benchmark"), 384, 2),
+              ("hooks4", "MIL_fc_mc", dict(n_classes=4), 1024, 4))
+
+EARLY_SEQS = {"loss": [(e, l, None) for e, l in enumerate([1.0, 0.9, 0.95, 0.97, 0.8, 0.85, 0.9, 0.95])],
+              "crit": [(e, 1.0, c) for e, c in enumerate([0.5, 0.0, 0.6, 0.6, 0.55, 0.7, 0.65, 0.6, 0.5])]}
+
+
+def hook_bags(seed, n, d, C):
+    return [(randn(seed + k, 40 + 7 * k, d), torch.tensor([k % C])) for k in range(n)]
+
+
+def check_case(got: dict, gold, name: str, atol=2e-5):
+    """Every array the reference produced for case `name` against what `got` holds."""
+    keys = [k for k in gold.files if k.startswith(name + ":") and k != name + ":psig"]
+    assert keys, name
+    for k in keys:
+        sub = k[len(name) + 1:]
+        assert sub in got, f"{name}: missing output {sub}"
+        exp, val = gold[k], np.asarray(got[sub])
+        if sub == "yhat":
+            assert np.array_equal(val.reshape(-1), exp.reshape(-1)), (name, val, exp)
+        else:
+            scale = max(1.0, float(np.abs(exp).max()))
+            np.testing.assert_allclose(val.reshape(exp.shape), exp, atol=atol * scale, rtol=0, err_msg=f"{name}:{sub}")
+
+
+class Loader(list):
+    """A list of (data, label) with room for the `.dataset` attribute `summary` reads."""

@@ -1,0 +1,109 @@
+"""SURVEY.md section 8 row f3 on the CPU: moc_amd's baseline models and trainer hooks against the
+fixtures the reference's own classes produced (tests/golden/baselines.npz), with the HIP pooling steps
+replaced by their CPU restatement (oracle/baselines_oracle.py).  Pins layers, mixing formulas,
+uncertainty factors, constructor RNG order, EarlyStopping and the train / validate / summary loops."""
+import contextlib
+import io
+import os
+import types
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+import torch.nn as nn
+
+import helpers as H
+import helpers_baselines as HB
+from oracle import baselines_oracle as BO
+
+GOLD = H.golden("baselines")
+
+
+def _ns(kind):
+    import moc_amd.model_adapters as A
+    import moc_amd.model_mil as Mm
+    return Mm if kind.startswith("MIL") else A
+
+
+@pytest.mark.parametrize("i", range(len(HB.BASELINE_CASES)), ids=[c[0] for c in HB.BASELINE_CASES])
+def test_baseline_models_match_reference_outputs(i):
+    name, kind, kw, N, label = HB.BASELINE_CASES[i]
+    seed = 4000 + 17 * i
+    with BO.patched(), contextlib.redirect_stdout(io.StringIO()):
+        cls, kwargs = HB.build_case(_ns(kind), kind, kw, seed)
+        model = cls(**kwargs)
+        np.testing.assert_allclose(HB.psig(model), GOLD[f"{name}:psig"], rtol=1e-6, atol=1e-7,
+                                   err_msg=f"{name}: same seed, different parameters (constructor RNG order)")
+        got = HB.run_case(model, kind, N, label, seed)
+    HB.check_case(got, GOLD, name)
+
+
+def run_hooks(core, mil_ns, tag, kind, kw, d, C, device, tmpdir):
+    torch.manual_seed(77)
+    model = getattr(mil_ns, kind)(**kw).to(device)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5)
+    tr, va = HB.Loader(HB.hook_bags(6000, 8, d, C)), HB.Loader(HB.hook_bags(6100, 8, d, C))
+    va.dataset = types.SimpleNamespace(slide_data=pd.DataFrame({"slide_id": [f"s{k}" for k in range(len(va))]}))
+    loss_fn = nn.CrossEntropyLoss()
+    with contextlib.redirect_stdout(io.StringIO()):
+        stop = core.EarlyStopping(patience=2, stop_epoch=1, verbose=True)
+        trace = []
+        for epoch in range(5):
+            core.train_loop(epoch, model, tr, opt, C, None, loss_fn)
+            fired = core.validate(0, epoch, model, va, C, stop, None, loss_fn, str(tmpdir))
+            trace.append([float(fired), stop.counter, float(stop.best_score), float(stop.val_loss_min)])
+            if fired:
+                break
+        res, err, auc, logger = core.summary(model, va, C)
+    assert os.path.exists(os.path.join(str(tmpdir), "s_0_checkpoint.pt"))
+    return dict(psig=HB.psig(model), trace=np.asarray(trace), summary=np.asarray([err, auc]),
+                acc=np.asarray([[logger.get_summary(i)[1], logger.get_summary(i)[2]] for i in range(C)], dtype=np.float64),
+                probs=np.stack([res[f"s{k}"]["prob"].reshape(-1) for k in range(len(va))]))
+
+
+def check_hooks(got, tag, tol=2e-5):
+    np.testing.assert_allclose(got["trace"], GOLD[f"{tag}:trace"], atol=tol, rtol=0, err_msg=f"{tag}: validate / early-stopping trace")
+    np.testing.assert_allclose(got["summary"], GOLD[f"{tag}:summary"], atol=tol, rtol=0)
+    np.testing.assert_array_equal(got["acc"], GOLD[f"{tag}:acc"])
+    np.testing.assert_allclose(got["probs"], GOLD[f"{tag}:probs"], atol=tol, rtol=0)
+    np.testing.assert_allclose(got["psig"], GOLD[f"{tag}:psig"], rtol=2e-5, atol=1e-6, err_msg=f"{tag}: parameters after training")
+
+
+@pytest.mark.parametrize("case", HB.HOOK_CASES, ids=[c[0] for c in HB.HOOK_CASES])
+def test_trainer_hooks_match_reference(case, tmp_path, monkeypatch):
+    import moc_amd.core_utils as core
+    import moc_amd.model_mil as Mm
+    monkeypatch.setattr(core, "_device", lambda: torch.device("cpu"))     # the product insists on a GPU; this is the CPU pin
+    with BO.patched():
+        got = run_hooks(core, Mm, *case, torch.device("cpu"), tmp_path)
+    check_hooks(got, case[0])
+
+
+@pytest.mark.parametrize("kind", list(HB.EARLY_SEQS))
+def test_early_stopping_sequences(kind, tmp_path):
+    import moc_amd.core_utils as core
+
+    class Dummy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = nn.Parameter(torch.zeros(1))
+    with contextlib.redirect_stdout(io.StringIO()):
+        es = core.EarlyStopping(patience=2, stop_epoch=3, verbose=True)
+        tr = []
+        for e, l, c in HB.EARLY_SEQS[kind]:
+            es(e, l, Dummy(), ckpt_name=os.path.join(str(tmp_path), "c.pt"), criteria=c)
+            tr.append([es.counter, float(es.best_score), float(es.early_stop), float(es.val_loss_min)])
+    np.testing.assert_allclose(np.asarray(tr), GOLD[f"early:{kind}"], atol=1e-12, rtol=0)
+
+
+def test_transmil_fails_loudly_without_nystrom_attention():
+    from moc_amd.model_mil import TransMIL
+    with pytest.raises((ImportError, NotImplementedError)):
+        TransMIL(n_classes=2)
+
+
+def test_product_pooling_refuses_cpu_tensors():
+    from moc_amd.pool_autograd import topk_mean_pool
+    with pytest.raises(AssertionError):
+        topk_mean_pool(torch.zeros(5, 2), 3)

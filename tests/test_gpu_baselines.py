@@ -1,0 +1,50 @@
+"""SURVEY.md section 8 row f3 on the GPU: the same cases as tests/test_baselines_cpu.py, with the top-j
+pooling / top-instance selection on the HIP path (moc_topk_mean through moc_amd.pool_autograd), forward
+AND backward, against the fixtures the reference's own classes produced."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+import helpers_baselines as HB
+from test_baselines_cpu import GOLD, _ns, check_hooks, run_hooks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("i", range(len(HB.BASELINE_CASES)), ids=[c[0] for c in HB.BASELINE_CASES])
+def test_baseline_models_on_the_hip_path(gpu_device, i):
+    name, kind, kw, N, label = HB.BASELINE_CASES[i]
+    seed = 4000 + 17 * i
+    dev = torch.device("cuda:0")
+    with contextlib.redirect_stdout(io.StringIO()):
+        cls, kwargs = HB.build_case(_ns(kind), kind, kw, seed, device=dev)
+        model = cls(**kwargs).to(dev)
+        # cached-sample initialisation standardises the samples on the GPU here (mean / std reductions in a
+        # different order than on the CPU): compare relative to each tensor's absolute sum
+        sig, exp = HB.psig(model.cpu()), GOLD[f"{name}:psig"]
+        assert np.all(np.abs(sig - exp) <= 5e-6 * exp[:, 1:2] + 1e-7), (name, sig, exp)
+        got = HB.run_case(model.to(dev), kind, N, label, seed, device=dev)
+    HB.check_case(got, GOLD, name, atol=5e-5)
+
+
+@pytest.mark.parametrize("case", HB.HOOK_CASES, ids=[c[0] for c in HB.HOOK_CASES])
+def test_trainer_hooks_on_the_hip_path(gpu_device, case, tmp_path):
+    import moc_amd.core_utils as core
+    import moc_amd.model_mil as Mm
+    got = run_hooks(core, Mm, *case, torch.device("cuda:0"), tmp_path)
+    check_hooks(got, case[0], tol=1e-4)
+
+
+def test_topk_mean_pool_gradient_is_the_gather_gradient(gpu_device):
+    from moc_amd.pool_autograd import topk_mean_pool
+    dev = torch.device("cuda:0")
+    x = HB.randn(5, 500, 7).to(dev).requires_grad_(True)
+    w = torch.arange(1, 8, device=dev, dtype=torch.float32)
+    (topk_mean_pool(x, 13) * w).sum().backward()
+    ref = x.detach().cpu().clone().requires_grad_(True)
+    (ref.topk(13, 0)[0].mean(0, keepdim=True) * w.cpu()).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref.grad.numpy(), atol=1e-7)
