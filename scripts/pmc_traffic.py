@@ -21,7 +21,7 @@ for tag, scale in (("fetch", 2.0), ("write", 1.0)):
     for (name, grid), v in groups.items():
         per_kernel.setdefault(f"{name} grid={grid}", {})[tag + "_bytes"] = statistics.median(v) * 1024 * scale
 k = [v for n, v in per_kernel.items() if n.startswith("scores_stream_kernel")][0]
-out = {"dtype": "bf16", "slides": 32, "patches": 15000, "kernel": "scores_stream_kernel<16,true>",
+out = {"dtype": "bf16", "slides": 32, "patches": 15000, "kernel": "scores_stream_kernel<16, true, 1, false>",
        "hbm_bytes_per_launch": int(k["fetch_bytes"] + k["write_bytes"]),
        "fetch_bytes_corrected_x2": int(k["fetch_bytes"]), "write_bytes": int(k["write_bytes"]),
        "note": "medians over 11 launches; FETCH_SIZE KiB x1024 x2 (gfx950 correction), WRITE_SIZE KiB x1024",
