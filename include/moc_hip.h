@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 7
+#define MOC_ABI_VERSION 8
 
 enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
 
@@ -246,6 +246,19 @@ int moc_p2p_step_supported(int C, int topk, int D, int topj);
 int moc_train_steps_p2p(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
                         const int64_t* labels, int slide0, int n, uint32_t use_bits,
                         moc_p2p_t* comm, moc_stream_t stream);
+
+/* f4: gated-attention MIL pooling, the aggregation of the ABMIL / CLAM baselines
+ * (models/model_clam.py:41-64 Attn_Net_Gated; :178-183, :206 CLAM_SB; :291-296, :318 CLAM_MB):
+ *   a = tanh(h Wa^T + ba), b = sigmoid(h Wb^T + bb)        [N, D]   (nn.Linear layout: Wa, Wb are [D, L])
+ *   A_raw[k][n] = Wc[k] . (a[n] * b[n]) + bc[k]             [K, N]   -- written (the reference returns it)
+ *   M[k] = sum_n softmax_n(A_raw[k])[n] * h[n]              [K, L]
+ * h: device fp32 [N, L] row-major, 16-byte aligned; L % 16 == 0; D in {128, 256, 384}; K <= 64.
+ * workspace: moc_gated_attention_workspace(N, L, D, K) bytes of device memory, 16-byte aligned. */
+size_t moc_gated_attention_workspace(int64_t N, int L, int D, int K);
+int moc_gated_attention_pool(const float* h, int64_t N, int L, const float* Wa, const float* ba,
+                             const float* Wb, const float* bb, int D, const float* Wc, const float* bc,
+                             int K, float* A_raw, float* M, void* workspace, size_t workspace_bytes,
+                             moc_stream_t stream);
 
 /* a10-a15 fused: `n` consecutive meta-steps (one slide each, slides slide0..slide0+n-1 in
  * order, one Adam step per slide: main_moc.py:380-410), parameters and Adam moments

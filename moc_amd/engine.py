@@ -347,3 +347,22 @@ def topk_mean(keys: torch.Tensor, vals: torch.Tensor, K: int, smallest=False, ke
                               int(K), int(bool(smallest)), ptr(pooled), ptr(idx), ptr(cnt), _stream()),
           "moc_topk_mean")
     return (pooled, idx, cnt) if want_idx else pooled
+
+
+def gated_attention_pool(h: torch.Tensor, Wa, ba, Wb, bb, Wc, bc):
+    """SURVEY.md section 8 row f4 (models/model_clam.py:41-64, :178-183, :206): h [N, L] fp32 on the GPU,
+    Wa / Wb [D, L], Wc [K, D] in nn.Linear layout.  -> (A_raw [K, N], M [K, L])."""
+    ts = [h, Wa, ba, Wb, bb, Wc, bc]
+    assert all(t.is_cuda and t.dtype == torch.float32 for t in ts), "gated_attention_pool: fp32 tensors on the GPU"
+    h, Wa, ba, Wb, bb, Wc, bc = [t.detach().contiguous() for t in ts]
+    N, L = h.shape
+    D, K = Wa.shape[0], Wc.shape[0]
+    assert Wa.shape == Wb.shape == (D, L) and Wc.shape == (K, D) and ba.numel() == bb.numel() == D and bc.numel() == K
+    dev = h.device
+    A_raw = torch.empty((K, N), dtype=torch.float32, device=dev)
+    M = torch.empty((K, L), dtype=torch.float32, device=dev)
+    nbytes = lib().moc_gated_attention_workspace(N, L, D, K)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    check(lib().moc_gated_attention_pool(ptr(h), N, L, ptr(Wa), ptr(ba), ptr(Wb), ptr(bb), D, ptr(Wc), ptr(bc), K,
+                                         ptr(A_raw), ptr(M), ptr(ws), nbytes, _stream()), "moc_gated_attention_pool")
+    return A_raw, M

@@ -426,8 +426,22 @@ def load_reference_baselines():
 
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from helpers_baselines import (BASELINE_CASES, HOOK_CASES, EARLY_SEQS, build_case, run_case, psig as _psig,  # noqa: E402
-                               randn as _randn, hook_bags, Loader)
+from helpers_baselines import (BASELINE_CASES, HOOK_CASES, EARLY_SEQS, CLAM_CASES, build_case, run_case, run_clam_case,  # noqa: E402
+                               psig as _psig, randn as _randn, hook_bags, Loader)
+
+
+def gen_clam():
+    """the reference's CLAM_SB / CLAM_MB (models/model_clam.py imports
+    utils.utils, which imports h5py-era helpers: AST extraction again)."""
+    base = dict(torch=torch, nn=nn, F=F, np=np, os=os)
+    util = _extract("utils/utils.py", ["initialize_weights"], dict(base))
+    ns = _extract("models/model_clam.py", ["Attn_Net", "Attn_Net_Gated", "CLAM_SB", "CLAM_MB"],
+                  dict(base, initialize_weights=util["initialize_weights"]))
+    arrays = {"cases": np.asarray([c[0] for c in CLAM_CASES])}
+    for i, (name, kind, kw, N, label, fkw) in enumerate(CLAM_CASES):
+        for k, v in run_clam_case(ns, kind, kw, N, label, fkw, 7000 + 13 * i).items():
+            arrays[f"{name}:{k}"] = v
+    save("clam", **arrays)
 
 
 def gen_baselines():
@@ -502,3 +516,4 @@ if __name__ == "__main__":
     gen_driver(ref)
     gen_summary()
     gen_baselines()
+    gen_clam()

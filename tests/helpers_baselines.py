@@ -138,7 +138,7 @@ def check_case(got: dict, gold, name: str, atol=2e-5):
         sub = k[len(name) + 1:]
         assert sub in got, f"{name}: missing output {sub}"
         exp, val = gold[k], np.asarray(got[sub])
-        if sub == "yhat":
+        if sub in ("yhat", "inst_labels", "inst_preds"):
             assert np.array_equal(val.reshape(-1), exp.reshape(-1)), (name, val, exp)
         else:
             scale = max(1.0, float(np.abs(exp).max()))
@@ -147,3 +147,46 @@ def check_case(got: dict, gold, name: str, atol=2e-5):
 
 class Loader(list):
     """A list of (data, label) with room for the `.dataset` attribute `summary` reads."""
+
+
+# ---------------------------------------------------------------- row f4: CLAM (gated-attention pooling)
+CLAM_CASES = [
+    # name, class, ctor kwargs, N, label, forward kwargs
+    ("sb_small", "CLAM_SB", dict(size_arg="small", n_classes=2), 300, 1, dict()),
+    ("sb_conch_inst", "CLAM_SB", dict(size_arg="conch", n_classes=3, subtyping=True, k_sample=8), 333, 2, dict(instance_eval=True, return_features=True)),
+    ("sb_bench_inst", "CLAM_SB", dict(size_arg="benchmark", n_classes=2, k_sample=8), 70, 0, dict(instance_eval=True)),
+    ("sb_tiny", "CLAM_SB", dict(size_arg="benchmark", n_classes=2, k_sample=8), 5, 1, dict(instance_eval=True)),      # N < k_sample
+    ("mb_small", "CLAM_MB", dict(size_arg="small", n_classes=3), 257, 1, dict()),
+    ("mb_conch_inst", "CLAM_MB", dict(size_arg="conch", n_classes=4, subtyping=True), 400, 3, dict(instance_eval=True, return_features=True)),
+    ("mb_big", "CLAM_MB", dict(size_arg="big", n_classes=2), 129, 0, dict(instance_eval=True)),
+]
+
+
+def run_clam_case(ns, kind, kw, N, label, fkw, seed, device="cpu"):
+    get = (lambda k: ns[k]) if isinstance(ns, dict) else (lambda k: getattr(ns, k))
+    torch.manual_seed(seed)
+    model = get(kind)(**kw)
+    sig = psig(model)
+    model = model.to(device)
+    d_in = model.attention_net[0].in_features
+    x = randn(seed + 100, N, d_in).to(device)
+    y = torch.tensor([label], device=device)
+    out = {"psig": sig}
+    logits, prob, yhat, A_raw, res = model(x, label=y, **fkw)
+    out.update(logits=logits.detach().cpu().numpy(), prob=prob.detach().cpu().numpy(), yhat=yhat.cpu().numpy().reshape(-1),
+               A_raw=A_raw.detach().cpu().numpy())
+    loss = F.cross_entropy(logits, y)
+    if fkw.get("instance_eval"):
+        out["instance_loss"] = np.asarray([float(res["instance_loss"].detach())])
+        out["inst_labels"] = np.asarray(res["inst_labels"]).reshape(-1)
+        out["inst_preds"] = np.asarray(res["inst_preds"]).reshape(-1)
+        loss = loss + 0.3 * res["instance_loss"]
+    if fkw.get("return_features"):
+        out["features"] = res["features"].detach().cpu().numpy()
+    out["loss"] = np.asarray([float(loss.detach())])
+    loss.backward()
+    for k, v in gsig(model).items():
+        out["grad:" + k] = v
+    out["attention_only"] = model(x, attention_only=True).detach().cpu().numpy()
+    out["patch_level"] = model.forward_patch_level(x).detach().cpu().numpy()[:16]
+    return out

@@ -107,3 +107,26 @@ def test_product_pooling_refuses_cpu_tensors():
     from moc_amd.pool_autograd import topk_mean_pool
     with pytest.raises(AssertionError):
         topk_mean_pool(torch.zeros(5, 2), 3)
+
+
+# ---------------------------------------------------------------- row f4: CLAM around the gated-attention step
+CLAM = H.golden("clam")
+
+
+def run_clam(i, device):
+    import moc_amd.model_clam as Mc
+    name, kind, kw, N, label, fkw = HB.CLAM_CASES[i]
+    return name, HB.run_clam_case(Mc, kind, kw, N, label, fkw, 7000 + 13 * i, device=device)
+
+
+def check_clam(name, got, atol):
+    np.testing.assert_allclose(got.pop("psig"), CLAM[f"{name}:psig"], rtol=1e-6, atol=1e-7,
+                               err_msg=f"{name}: same seed, different parameters")
+    HB.check_case(got, CLAM, name, atol=atol)
+
+
+@pytest.mark.parametrize("i", range(len(HB.CLAM_CASES)), ids=[c[0] for c in HB.CLAM_CASES])
+def test_clam_models_match_reference_outputs(i):
+    with BO.patched():
+        name, got = run_clam(i, "cpu")
+    check_clam(name, got, 2e-5)

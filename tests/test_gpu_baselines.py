@@ -48,3 +48,46 @@ def test_topk_mean_pool_gradient_is_the_gather_gradient(gpu_device):
     ref = x.detach().cpu().clone().requires_grad_(True)
     (ref.topk(13, 0)[0].mean(0, keepdim=True) * w.cpu()).sum().backward()
     np.testing.assert_allclose(x.grad.cpu().numpy(), ref.grad.numpy(), atol=1e-7)
+
+
+# ---------------------------------------------------------------- row f4: gated-attention pooling kernel
+@pytest.mark.parametrize("N,L,D,K", [(1, 512, 256, 1), (63, 512, 256, 1), (64, 512, 384, 3), (1000, 512, 384, 1),
+                                     (4097, 1024, 128, 2), (15000, 512, 384, 1), (777, 64, 256, 5)])
+def test_gated_attention_pool_matches_restatement(gpu_device, N, L, D, K):
+    from moc_amd import engine
+    from oracle import baselines_oracle as BO
+    g = lambda s, *shape: HB.randn(s, *shape)
+    h = torch.relu(g(1, N, L))                                    # CLAM feeds ReLU features
+    Wa, Wb = g(2, D, L) * (2.0 / (L + D)) ** 0.5, g(3, D, L) * (2.0 / (L + D)) ** 0.5
+    ba, bb = g(4, D) * 0.1, g(5, D) * 0.1
+    Wc, bc = g(6, K, D) * (2.0 / (D + K)) ** 0.5 * 3.0, g(7, K) * 0.1
+    A_ref, M_ref = BO.gated_attention_pool(h.double(), Wa.double(), ba.double(), Wb.double(), bb.double(), Wc.double(), bc.double())
+    dev = torch.device("cuda:0")
+    A, M = engine.gated_attention_pool(*[t.to(dev) for t in (h, Wa, ba, Wb, bb, Wc, bc)])
+    np.testing.assert_allclose(A.cpu().numpy(), A_ref.float().numpy(), atol=1e-4, rtol=0)
+    np.testing.assert_allclose(M.cpu().numpy(), M_ref.float().numpy(), atol=1e-4, rtol=0)
+
+
+def test_gated_attention_pool_survives_large_scores(gpu_device):
+    """Online softmax: scores of +-80 must neither overflow nor lose the dominant rows."""
+    from moc_amd import engine
+    from oracle import baselines_oracle as BO
+    N, L, D = 500, 512, 256
+    h = torch.relu(HB.randn(11, N, L))
+    Wa, Wb = HB.randn(12, D, L) * 0.05, HB.randn(13, D, L) * 0.05
+    ba, bb, bc = torch.zeros(D), torch.zeros(D), torch.zeros(1)
+    Wc = HB.randn(14, 1, D) * 20.0
+    A_ref, M_ref = BO.gated_attention_pool(h.double(), Wa.double(), ba.double(), Wb.double(), bb.double(), Wc.double(), bc.double())
+    assert float(A_ref.abs().max()) > 60
+    dev = torch.device("cuda:0")
+    A, M = engine.gated_attention_pool(*[t.to(dev) for t in (h, Wa, ba, Wb, bb, Wc, bc)])
+    assert torch.isfinite(M).all()
+    np.testing.assert_allclose(A.cpu().numpy(), A_ref.float().numpy(), atol=2e-3, rtol=0)
+    np.testing.assert_allclose(M.cpu().numpy(), M_ref.float().numpy(), atol=5e-3, rtol=0)
+
+
+@pytest.mark.parametrize("i", range(len(HB.CLAM_CASES)), ids=[c[0] for c in HB.CLAM_CASES])
+def test_clam_models_on_the_hip_path(gpu_device, i):
+    from test_baselines_cpu import check_clam, run_clam
+    name, got = run_clam(i, torch.device("cuda:0"))
+    check_clam(name, got, 1e-4)
