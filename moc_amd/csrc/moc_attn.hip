@@ -46,12 +46,51 @@ __global__ __launch_bounds__(256) void attn_image_kernel(const float* Wa, const 
     reinterpret_cast<float4*>(img)[idx] = v;
 }
 
+// B fragments from LDS, issued by hand one pair of n-tiles ahead of the MFMAs that use them and awaited with a
+// counted lgkmcnt (LDS returns in order; the LDS-DMA of the next stage counts on vmcnt, not here).  Left to
+// hipcc the loop is "2 reads, wait, 8 MFMAs": the read latency is exposed once per 256 cycles of matrix work.
+typedef unsigned __attribute__((ext_vector_type(4))) au32x4_t;
+template <int OFF>
+__device__ __forceinline__ void at_lds16(au32x4_t& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int KEEP>
+__device__ __forceinline__ void at_wait(au32x4_t& x, au32x4_t& y) {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(KEEP) : "memory");
+    asm volatile("" : "+v"(x));
+    asm volatile("" : "+v"(y));
+}
+template <int Q, int NQ>
+__device__ __forceinline__ void at_pairs(f32x4_t (&acc)[NQ], const float4& xa, unsigned base, au32x4_t& b0, au32x4_t& b1,
+                                         au32x4_t& n0, au32x4_t& n1) {
+    if constexpr (Q < NQ) {
+        if constexpr (Q + 2 < NQ) {
+            at_lds16<(Q + 2) * 1024>(n0, base);
+            at_lds16<(Q + 3) * 1024>(n1, base);
+            at_wait<2>(b0, b1);
+        } else {
+            at_wait<0>(b0, b1);
+        }
+        const float xs[4] = {xa.x, xa.y, xa.z, xa.w};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {                                 // two independent accumulators alternate
+            acc[Q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[m], __uint_as_float(b0[m]), acc[Q], 0, 0, 0);
+            acc[Q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[m], __uint_as_float(b1[m]), acc[Q + 1], 0, 0, 0);
+        }
+        at_pairs<Q + 2, NQ>(acc, xa, base, n0, n1, b0, b1);
+    }
+}
+
+// gate nonlinearities on the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1e-7 absolute on outputs in [-1, 1])
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+
 template <int ND>
 __global__ __launch_bounds__(256, 1) void gated_attention_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int STAGE_VEC = 2 * ND * 64;                            // float4 per stage (16 columns of L)
-    float4* stage = reinterpret_cast<float4*>(smem);                 // [2][STAGE_VEC]
-    float* score_s = reinterpret_cast<float*>(smem + 2 * STAGE_VEC * 16);   // [K][AT_ROWS]
+    float4* stage = reinterpret_cast<float4*>(smem);                 // [2][STAGE_VEC weights + 256 A fragments]
+    float* score_s = reinterpret_cast<float*>(smem + 2 * (STAGE_VEC + 256) * 16);   // [K][AT_ROWS]
     float* prob_s = score_s + (size_t)a.K * AT_ROWS;                        // [AT_ROWS]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = a.L, K = a.K, T = L / 16;
@@ -65,36 +104,42 @@ __global__ __launch_bounds__(256, 1) void gated_attention_kernel(AttnArgs a) {
 #pragma unroll
     for (int q = 0; q < 2 * ND; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // stage 0 and the first A fragment
-    for (int i = threadIdx.x; i < STAGE_VEC; i += 256) stage[i] = img[i];
-    float4 xa = *reinterpret_cast<const float4*>(hp);
-    __syncthreads();
+    // Weight stages AND the workgroup's A fragments go global -> LDS directly (global_load_lds_dwordx4: no
+    // VGPR in between -- with 2 * ND accumulator tiles per wave there are none to spare; register staging
+    // spilled to scratch and ran 3.5x slower; an A fragment prefetched into registers was spilled too and its
+    // reload's vmcnt(0) drained the weight DMA early).  One instruction moves 64 lanes x 16 B: the weight
+    // image is copied as it lies; lane (row, kq) fetches h[row][16t + 4kq ..+3] into slot [wave][lane].
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int PER = STAGE_VEC / 256;                              // weight instructions per wave per stage
+    constexpr int BUF_VEC = STAGE_VEC + 256;                          // + 4 waves x 64 A fragments
+    auto issue_stage = [&](int t, int buf) {
+        float4* dst = stage + buf * BUF_VEC;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int v = q * 256 + wave * 64;                        // first float4 of this wave's piece
+            __builtin_amdgcn_global_load_lds((gptr_t)(img + (int64_t)t * STAGE_VEC + v + lane), (lptr_t)(dst + v), 16, 0, 0);
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)(hp + t * 16), (lptr_t)(dst + STAGE_VEC + wave * 64), 16, 0, 0);
+    };
+    issue_stage(0, 0);
+    __syncthreads();                                                  // (its fence waits for the LDS-DMA: vmcnt(0))
     for (int t = 0; t < T; ++t) {
-        const float4* cur = stage + (t & 1) * STAGE_VEC;
-        float4* nxt = stage + ((t + 1) & 1) * STAGE_VEC;
-        // request the next stage and the next A fragment before this stage's MFMAs
-        constexpr int PER = STAGE_VEC / 256;                          // float4 per thread per stage (2*ND/4)
-        float4 pre[PER];
-        float4 xn = xa;
-        if (t + 1 < T) {
-#pragma unroll
-            for (int q = 0; q < PER; ++q) pre[q] = img[(int64_t)(t + 1) * STAGE_VEC + q * 256 + threadIdx.x];
-            xn = *reinterpret_cast<const float4*>(hp + (t + 1) * 16);
+        const float4* cur = stage + (t & 1) * BUF_VEC;
+        if (t + 1 < T) issue_stage(t + 1, (t + 1) & 1);               // in flight behind this stage's MFMAs
+        {
+            // every LDS read of the loop is hand-issued: an ordinary read would make hipcc wait vmcnt(0) first
+            // (the DMA just issued writes LDS; it cannot tell the two buffers apart) and the overlap is gone
+            const unsigned base = (unsigned)(uintptr_t)(cur + lane);
+            au32x4_t xr, b0, b1, n0, n1;
+            at_lds16<0>(xr, (unsigned)(uintptr_t)(cur + STAGE_VEC + wave * 64 + lane));
+            at_lds16<0>(b0, base);
+            at_lds16<1024>(b1, base);
+            at_wait<2>(xr, xr);
+            const float4 xa = {__uint_as_float(xr[0]), __uint_as_float(xr[1]), __uint_as_float(xr[2]), __uint_as_float(xr[3])};
+            at_pairs<0, 2 * ND>(acc, xa, base, b0, b1, n0, n1);
         }
-#pragma unroll
-        for (int q = 0; q < 2 * ND; ++q) {
-            const float4 bv = cur[q * 64 + lane];
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, bv.x, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, bv.y, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, bv.z, acc[q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, bv.w, acc[q], 0, 0, 0);
-        }
-        if (t + 1 < T) {
-#pragma unroll
-            for (int q = 0; q < PER; ++q) nxt[q * 256 + threadIdx.x] = pre[q];
-        }
-        xa = xn;
-        __syncthreads();                                              // next stage visible; this one free to overwrite
+        __syncthreads();                                              // next stage landed and visible; this one free
     }
 
     // ---- gate and scores.  acc[q][i]: row (lane >> 4) * 4 + i of the wave's 16, column q*16 + (lane & 15)
@@ -105,7 +150,7 @@ __global__ __launch_bounds__(256, 1) void gated_attention_kernel(AttnArgs a) {
         const float wa = a.ba[d], wb = a.bb[d];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            acc[q][i] = tanhf(acc[q][i] + wa) * (1.f / (1.f + expf(-(acc[ND + q][i] + wb))));
+            acc[q][i] = fast_tanh(acc[q][i] + wa) * fast_sigmoid(acc[ND + q][i] + wb);
     }
     for (int k = 0; k < K; ++k) {
         float part[4] = {0.f, 0.f, 0.f, 0.f};
@@ -147,20 +192,38 @@ __global__ __launch_bounds__(256, 1) void gated_attention_kernel(AttnArgs a) {
             a.ws_m[(int64_t)blockIdx.x * K + k] = m;
             a.ws_l[(int64_t)blockIdx.x * K + k] = l;
         }
-        for (int c = threadIdx.x; c < L; c += 256) {
-            float sum = 0.f;
-            for (int r = 0; r < nrow; ++r) sum = fmaf(prob_s[r], a.h[(row0 + r) * L + c], sum);
-            a.ws_M[((int64_t)blockIdx.x * K + k) * L + c] = sum;
+        for (int c = threadIdx.x * 4; c < L; c += 1024) {              // float4 columns, 8 rows in flight
+            float4 sum = {0.f, 0.f, 0.f, 0.f};
+            int r = 0;
+            for (; r + 8 <= nrow; r += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(a.h + (row0 + r + u) * L + c);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float p = prob_s[r + u];
+                    sum.x = fmaf(p, v[u].x, sum.x); sum.y = fmaf(p, v[u].y, sum.y);
+                    sum.z = fmaf(p, v[u].z, sum.z); sum.w = fmaf(p, v[u].w, sum.w);
+                }
+            }
+            for (; r < nrow; ++r) {
+                const float4 v = *reinterpret_cast<const float4*>(a.h + (row0 + r) * L + c);
+                const float p = prob_s[r];
+                sum.x = fmaf(p, v.x, sum.x); sum.y = fmaf(p, v.y, sum.y); sum.z = fmaf(p, v.z, sum.z); sum.w = fmaf(p, v.w, sum.w);
+            }
+            *reinterpret_cast<float4*>(a.ws_M + ((int64_t)blockIdx.x * K + k) * L + c) = sum;
         }
         __syncthreads();
     }
 }
 
-// grid (K): merge the G per-workgroup triples of head k
+// grid (K, ceil(L / 64)): merge the G per-workgroup triples of head k for 64 columns.  Thread = (column,
+// one of four interleaved slices of the workgroups); the four partial sums meet in LDS in a fixed order.
 __global__ __launch_bounds__(256) void attention_merge_kernel(const float* ws_m, const float* ws_l, const float* ws_M,
                                                               int G, int K, int L, float* M) {
+    extern __shared__ float scale_s[];                               // [G] exp(m_g - m), then [4][64] partials
     __shared__ float red[256];
-    const int k = blockIdx.x;
+    const int k = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     float m = -INFINITY;
     for (int g = threadIdx.x; g < G; g += 256) m = fmaxf(m, ws_m[(int64_t)g * K + k]);
     red[threadIdx.x] = m;
@@ -172,7 +235,11 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const float* ws_m,
     m = red[0];
     __syncthreads();
     float l = 0.f;
-    for (int g = threadIdx.x; g < G; g += 256) l += expf(ws_m[(int64_t)g * K + k] - m) * ws_l[(int64_t)g * K + k];
+    for (int g = threadIdx.x; g < G; g += 256) {
+        const float sc = expf(ws_m[(int64_t)g * K + k] - m);
+        scale_s[g] = sc;
+        l += sc * ws_l[(int64_t)g * K + k];
+    }
     red[threadIdx.x] = l;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -180,11 +247,22 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const float* ws_m,
         __syncthreads();
     }
     l = red[0];
-    for (int c = threadIdx.x; c < L; c += 256) {
-        float s = 0.f;
-        for (int g = 0; g < G; ++g) s = fmaf(expf(ws_m[(int64_t)g * K + k] - m), ws_M[((int64_t)g * K + k) * L + c], s);
-        M[(int64_t)k * L + c] = s / l;
+    __syncthreads();
+    float s = 0.f;
+    if (c < L) {
+        int g = slice;
+        for (; g + 12 < G; g += 16) {                                // four independent loads in flight
+            const float v0 = ws_M[((int64_t)g * K + k) * L + c], v1 = ws_M[((int64_t)(g + 4) * K + k) * L + c];
+            const float v2 = ws_M[((int64_t)(g + 8) * K + k) * L + c], v3 = ws_M[((int64_t)(g + 12) * K + k) * L + c];
+            s = fmaf(scale_s[g], v0, s); s = fmaf(scale_s[g + 4], v1, s);
+            s = fmaf(scale_s[g + 8], v2, s); s = fmaf(scale_s[g + 12], v3, s);
+        }
+        for (; g < G; g += 4) s = fmaf(scale_s[g], ws_M[((int64_t)g * K + k) * L + c], s);
     }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (slice == 0 && c < L)
+        M[(int64_t)k * L + c] = (((red[threadIdx.x] + red[threadIdx.x + 64]) + red[threadIdx.x + 128]) + red[threadIdx.x + 192]) / l;
 }
 
 size_t attn_ws_floats(int64_t N, int L, int D, int K) {
@@ -224,7 +302,7 @@ extern "C" int moc_gated_attention_pool(const float* h, int64_t N, int L, const 
     const int64_t nvec = (int64_t)(L / 16) * 2 * (D / 16) * 64;
     attn_image_kernel<<<moc_cdiv(nvec, 256), 256, 0, s>>>(Wa, Wb, L, D, img);
     MOC_CHECK_LAUNCH("moc_gated_attention_pool(image)");
-    const size_t smem = (size_t)2 * (2 * (D / 16) * 64) * 16 + (size_t)(K + 1) * AT_ROWS * sizeof(float);
+    const size_t smem = (size_t)2 * (2 * (D / 16) * 64 + 256) * 16 + (size_t)(K + 1) * AT_ROWS * sizeof(float);
 #define MOC_LAUNCH_ATTN(NDV)                                                                                         \
     do {                                                                                                             \
         static bool attr_set = false;                                                                                \
@@ -239,7 +317,7 @@ extern "C" int moc_gated_attention_pool(const float* h, int64_t N, int L, const 
     else MOC_LAUNCH_ATTN(24);
 #undef MOC_LAUNCH_ATTN
     MOC_CHECK_LAUNCH("moc_gated_attention_pool");
-    attention_merge_kernel<<<K, 256, 0, s>>>(a.ws_m, a.ws_l, a.ws_M, G, K, L, M);
+    attention_merge_kernel<<<dim3(K, moc_cdiv(L, 64)), 256, (size_t)G * sizeof(float), s>>>(a.ws_m, a.ws_l, a.ws_M, G, K, L, M);
     MOC_CHECK_LAUNCH("moc_gated_attention_pool(merge)");
     return MOC_OK;
 }
