@@ -20,8 +20,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-SIZES = [900, 1100, 1000, 800, 950, 1050, 700, 1200]      # 2 ranks x 4 synchronous steps
-T = len(SIZES) // 2
+SIZES = [900, 1100, 1000, 800, 950, 1050, 700, 1200, 850, 1150, 990, 760]      # world x T slides: step t uses slides [t*world, (t+1)*world)
+
+
+def _steps(world):
+    return len(SIZES) // world
 
 
 def _worker(rank, world, port, q, exchange):
@@ -38,7 +41,8 @@ def _worker(rank, world, port, q, exchange):
         W, We = synth.make_bank(77, 512, C)
         sizes = SIZES
         bags, labels = synth.make_slide_set(7700, sizes, 512, We, C)
-        mine = [rank + 2 * t for t in range(T)]                   # step t uses slide t of every rank
+        T = _steps(world)
+        mine = [rank + world * t for t in range(T)]               # step t uses slide t of every rank
         torch.manual_seed(5)
         model = M.senet(512, 4).to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
@@ -50,7 +54,7 @@ def _worker(rank, world, port, q, exchange):
         assert mdist.exchange_error() == 0
         losses = mdist.train_dp.last[0].meta_ws()[0]["loss"].cpu().numpy()
         ev = mdist.evaluation_dp(model, res, dev, H.make_args(C, j, K), labels, mine,
-                                 [[2 * t for t in range(T)], [1 + 2 * t for t in range(T)]])
+                                 [[r + world * t for t in range(T)] for r in range(world)])
         q.put((rank, (H.flat_params(model), losses, ev, int(float(opt.state[next(model.parameters())]["step"])),
                       mdist.train_dp.exchange)))
         mdist.shutdown()
@@ -60,34 +64,37 @@ def _worker(rank, world, port, q, exchange):
         q.put((rank, "ERR " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("exchange", ["auto", "rccl"])
-def test_train_dp_two_ranks_matches_batch2_oracle(gpu_device, exchange):
+@pytest.mark.parametrize("exchange,world", [("auto", 2), ("rccl", 2), ("auto", 4)])
+def test_train_dp_matches_minibatch_oracle(gpu_device, exchange, world):
     import helpers as H
     from moc_amd import synth
     from oracle import moc_oracle as O
     ctx = mp.get_context("spawn")
     q, port = ctx.Queue(), _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
+    T = _steps(world)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
-    out = dict(q.get(timeout=300) for _ in range(2))
+    out = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
     for r, v in out.items():
         assert not isinstance(v, str), f"rank {r}: {v}"
-    assert np.array_equal(out[0][0], out[1][0]), "ranks hold different parameters after the all-reduced steps"
-    assert out[0][3] == T and out[1][3] == T
-    # the path asked for is the path taken (auto = the in-kernel exchange on one node)
-    assert out[0][4] == out[1][4] == ("p2p" if exchange == "auto" else "collective")
+    for r in range(1, world):
+        assert np.array_equal(out[0][0], out[r][0]), "ranks hold different parameters after the summed-gradient steps"
+    for r in range(world):
+        assert out[r][3] == T
+        # the path asked for is the path taken (auto = the in-kernel exchange on one node)
+        assert out[r][4] == ("p2p" if exchange == "auto" else "collective")
     # oracle: T synchronous steps, each the mean gradient of one slide per rank
     C, j, K = 2, 100, 10
     W, We = synth.make_bank(77, 512, C)
     sizes = SIZES
     bags, labels = synth.make_slide_set(7700, sizes, 512, We, C)
     masks = {}
-    for rank in range(2):
+    for rank in range(world):
         torch.manual_seed(100 + rank)
-        for i in [rank + 2 * t for t in range(T)]:
+        for i in [rank + world * t for t in range(T)]:
             masks[i] = O.draw_mask(sizes[i])
     torch.manual_seed(5)
     ref = O.Senet(512, 4)
@@ -95,21 +102,21 @@ def test_train_dp_two_ranks_matches_batch2_oracle(gpu_device, exchange):
     ref_losses = {}
     for t in range(T):
         grads = []
-        for rank in range(2):
-            i = rank + 2 * t
+        for rank in range(world):
+            i = rank + world * t
             sr = O.slide_process(bags[i], W, We, C, j, mask=masks[i])
             pooled = O.pool_top(O.mix_train(ref(sr["selected_feat"]), sr), [K])[1][K]
             loss = torch.nn.functional.cross_entropy(pooled, torch.tensor([labels[i]]))
-            ref_losses[i] = float(loss)
+            ref_losses[i] = float(loss.detach())
             grads.append(torch.autograd.grad(loss, list(ref.parameters())))
-        for p, g0, g1 in zip(ref.parameters(), *grads):
-            p.grad = (g0 + g1) / 2
+        for p, *gs in zip(ref.parameters(), *grads):
+            p.grad = sum(gs) / world
         ropt.step()
-    for rank in range(2):
-        np.testing.assert_allclose(out[rank][1], [ref_losses[rank + 2 * t] for t in range(T)], atol=1e-4)
+    for rank in range(world):
+        np.testing.assert_allclose(out[rank][1], [ref_losses[rank + world * t] for t in range(T)], atol=1e-4)
     H.assert_adam_params_close(out[0][0], H.flat_params(ref), H.flat_state(ropt, "exp_avg_sq"), step=T,
-                               grad_noise=1e-6, what="dp2")
+                               grad_noise=1e-6, what=f"dp{world}")
     ev_ref = O.evaluation(ref, bags, labels, W, We, C, j, K)
-    for rank in range(2):
+    for rank in range(world):
         ev = out[rank][2]
         assert abs(ev["loss"] - ev_ref["loss"]) < 1e-4 and ev["acc"] == ev_ref["acc"] and abs(ev["auc"] - ev_ref["auc"]) < 2e-3
