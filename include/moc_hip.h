@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 8
+#define MOC_ABI_VERSION 9
 
 enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
 
@@ -114,7 +114,6 @@ typedef struct moc_meta_ws {
     float*   loss;      /* [n_slides]       cross entropy                                    */
     int32_t* pred;      /* [n_slides]       argmax of pooled                                 */
     float*   pair_dh;   /* [C*topk, H]      backward scratch (one slide at a time)           */
-    float*   pair_x;    /* [C*topk, D]      the pairs' bag rows as fp32 (gathered once per step)    */
     float*   W2_alt;    /* [4, H]           second copy of W2: the one-launch step reads one and writes
                                             the other (may be NULL: three-launch step is used)      */
     int64_t* pair_row;  /* [C*topk]                                                          */

@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 MOC_F32, MOC_BF16, MOC_F16 = 0, 1, 2
 SEL_BITS = {"topk": 1, "delta_softmax": 2, "delta_diff": 4, "bottomk": 8}
@@ -45,7 +45,7 @@ class MocMeta(C.Structure):
 
 class MocMetaWs(C.Structure):
     _fields_ = [(n, _p) for n in ("H1", "gates", "mixed", "pooled", "topk_idx", "topk_cnt",
-                                  "loss", "pred", "pair_dh", "pair_x", "W2_alt", "pair_row", "n_pair")]
+                                  "loss", "pred", "pair_dh", "W2_alt", "pair_row", "n_pair")]
 
 
 # name -> (restype, argtypes); every symbol include/moc_hip.h declares

@@ -284,7 +284,6 @@ struct FinishArgs {
     float *m_W2, *m_b2, *m_b1, *v_W2, *v_b2, *v_b1;
     float *g_W2, *g_b2, *g_b1;
     float* pair_dh;
-    float* pair_x;                  // fused kernel: [C*K][D] fp32 rows of the pairs
     const unsigned char* X;
     int64_t* pair_row;
     int32_t* n_pair;
@@ -971,7 +970,6 @@ struct W1Args {
     const int32_t* n_pair;
     float *W1, *m_W1, *v_W1, *g_W1;
     unsigned char* W1img;   // kept in sync with W1 when the step is applied (nullable)
-    const float* pair_x;    // [P][D] fp32 rows gathered by the fused step (nullable: gather here)
     int D, apply_adam;
     int P_static;           // >= 0: pair count known to the host (padded list), else read n_pair
     AdamCoef adam;
@@ -1003,10 +1001,7 @@ __global__ __launch_bounds__(256) void w1_update_kernel(W1Args a) {
     for (int p0 = 0; p0 < P; p0 += W1_MAXP) {
         const int np = P - p0 < W1_MAXP ? P - p0 : W1_MAXP;
         if (p0 > 0) __syncthreads();
-        if (a.pair_x) {
-#pragma unroll 8
-            for (int p = 0; p < np; ++p) xs[p][threadIdx.x] = a.pair_x[(int64_t)(p0 + p) * a.D + d];
-        } else {
+        {
             // 16-B loads, all independent: LPR lanes cover one row's 256 columns, 256/LPR rows per round
             if (threadIdx.x < np) prow_s[threadIdx.x] = a.pair_row[p0 + threadIdx.x];
             __syncthreads();
@@ -1192,7 +1187,7 @@ int launch_pool_finish(const moc_batch_t* B, const moc_meta_t* M, const moc_meta
     a.pair_dh = ws->pair_dh; a.pair_row = ws->pair_row; a.n_pair = ws->n_pair;
     a.stride = B->total_rows; a.C = B->C; a.K = B->topk; a.slide0 = slide0; a.train = train;
     a.apply_adam = apply_adam; a.use_bits = use_bits; a.adam = k;
-    a.pair_x = ws->pair_x; a.X = (const unsigned char*)B->X; a.D = B->D; a.xdt = B->dtype;   /* storage code: 0 f32, 1 bf16, 2 f16 */
+    a.X = (const unsigned char*)B->X; a.D = B->D; a.xdt = B->dtype;   /* storage code: 0 f32, 1 bf16, 2 f16 */
     a.base_host = -1; a.seg_host = 0;
     if (n == 1 && B->row_off_host) {
         a.base_host = B->row_off_host[slide0];
@@ -1264,8 +1259,8 @@ int launch_w1(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws
               const AdamCoef& k, hipStream_t s, bool padded_pairs) {
     W1Args a;
     a.P_static = padded_pairs ? B->C * B->topk : -1;
-    a.pair_x = nullptr;      // measured: gathering the pairs' rows in the single-workgroup step kernel
-                             // costs it more (+2 us) than this kernel saves (-1.4 us); gather here
+    // (measured: gathering the pairs' rows in the single-workgroup step kernel for this kernel costs
+    // more there (+2 us) than it saves here (-1.4 us): the rows are gathered here)
     a.W1img = (unsigned char*)M->W1_image;
     a.X = (const unsigned char*)B->X; a.pair_dh = ws->pair_dh; a.pair_row = ws->pair_row; a.n_pair = ws->n_pair;
     a.W1 = M->W1; a.m_W1 = M->m_W1; a.v_W1 = M->v_W1; a.g_W1 = M->g_W1; a.D = B->D; a.apply_adam = apply_adam; a.adam = k;

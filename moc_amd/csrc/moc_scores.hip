@@ -349,7 +349,10 @@ __device__ __forceinline__ void compute_pairs_impl(const u32x4_t (&buf)[NF], u32
     }
 }
 
-// ---- streaming form for Ct <= 16 (one n-tile): persistent workgroups ---------------
+// ---- streaming form: persistent workgroups ------------------------------------------
+// (A second load shape was built and measured against this one -- whole-row contiguous loads staged
+// through a swizzled LDS tile with the bank image in registers: a tie on large batches, slower on the
+// 32-slide masked launch (3.9 vs 5.1 TB/s).  It is gone from the tree; DESIGN.md section 5 has the numbers.)
 // The generic kernel above leaves the load schedule to the compiler, which keeps two
 // 1-KiB loads in flight per wave (24 KB per CU: ~3 TB/s).  Here every wave walks a flat
 // list of 16-row tiles (all slides of the batch), the bank image is staged once per
@@ -518,152 +521,6 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
     }
 }
 
-// ---- row-contiguous form (Ct <= 16, rows of 1 or 2 KiB) ------------------------------------
-// The streaming kernel above reads A fragments straight from HBM: every wave-load touches 16 rows
-// x 64 B, twice the cache-line lookups of a contiguous KiB, and the address unit -- not HBM -- sets
-// the pace at ~4.8 TB/s.  Here a wave-load is ONE whole KiB of ONE row (scalar row base + lane*16);
-// the 16 rows of a tile are written to a per-wave LDS tile with the 16-B chunk index XOR-ed by the
-// row (bank-conflict-free for the write and for the fragment read lane l -> row l&15, chunk
-// 4*kk + (l>>4)), and the bank image lives in registers (one wave per SIMD: 512 VGPRs to spend).
-// Same flat tile walk, same hand-counted waits, same epilogue as the streaming kernel.
-template <int OFF>
-__device__ __forceinline__ void asm_load16_s(u32x4_t& dst, unsigned voff, const unsigned char* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
-}
-
-template <int U, bool BF16>
-__global__ __launch_bounds__(256, 1) void scores_rows_kernel(ScoresArgs a, int n_slides) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int ESZ = BF16 ? 2 : 4;
-    constexpr int NB = BF16 ? 48 : 16;                 // bank fragments per KiB unit per lane
-    constexpr int NL = 16 * U;                         // loads per tile per lane (16 rows x U units)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row_bytes = (int64_t)a.D * ESZ;      // == U * 1024
-    constexpr int LDT = 17;
-    uint4* tileA = reinterpret_cast<uint4*>(smem) + wave * 16 * 64;                      // [16 rows][64 chunks]
-    float* tile = reinterpret_cast<float*>(smem + 4 * 16 * 1024) + wave * 16 * LDT;
-    int64_t* s_base = reinterpret_cast<int64_t*>(smem + 4 * 16 * 1024 + 4 * 16 * LDT * sizeof(float));
-    int64_t* s_xbase = s_base + n_slides;
-    int* prefix = reinterpret_cast<int*>(s_xbase + n_slides);
-    int* s_nk = prefix + n_slides + 1;
-
-    u32x4_t bank[U * NB];                               // B operand, whole image, in registers
-    {
-        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(a.bank) + lane;
-#pragma unroll
-        for (int q = 0; q < U * NB; ++q) bank[q] = src[q * 64];
-    }
-    for (int b = threadIdx.x; b < n_slides; b += 256) {
-        const int64_t base = a.row_off[b];
-        s_base[b] = base;
-        s_xbase[b] = a.x_off ? a.x_off[b] : base;
-        s_nk[b] = a.kept ? a.n_kept[b] : (int)(a.row_off[b + 1] - base);
-    }
-    __syncthreads();
-    if (wave == 0) {   // prefix[b] = tiles of slides < b
-        int carry = 0;
-        for (int c0 = 0; c0 < n_slides; c0 += 64) {
-            const int b = c0 + lane;
-            int v = 0;
-            if (b < n_slides) v = (s_nk[b] + 15) >> 4;
-            int inc = v;
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += o;
-            }
-            if (b < n_slides) prefix[b + 1] = carry + inc;
-            carry += __shfl(inc, 63, 64);
-        }
-        if (lane == 0) prefix[0] = 0;
-    }
-    __syncthreads();
-    const int total = prefix[n_slides];
-    const int stride = gridDim.x * 4;
-    typedef const int32_t __attribute__((address_space(4))) * kept_sptr;
-    kept_sptr kept_s = (kept_sptr)(uintptr_t)a.kept;
-    const unsigned voff = (unsigned)lane * 16u;
-
-    struct Tile { int64_t base; int row0, nk; };
-    auto issue = [&](int g, Tile& t, u32x4_t (&buf)[NL]) {
-        int lo = 0, hi = n_slides;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= g) lo = mid; else hi = mid; }
-        const int b = __builtin_amdgcn_readfirstlane(lo);
-        t.base = s_base[b];
-        const int64_t xbase = s_xbase[b];
-        t.nk = __builtin_amdgcn_readfirstlane(s_nk[b]);
-        t.row0 = __builtin_amdgcn_readfirstlane((g - prefix[b]) * 16);
-        const int last_valid = t.nk - 1 - t.row0;              // >= 0: the tile exists
-        int k[16];
-        if (a.kept) {
-            const int idx = __builtin_amdgcn_readfirstlane((int)t.base + t.row0);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { k[i] = kept_s[idx + i]; asm volatile("" : "+s"(k[i])); }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) k[i] = t.row0 + i;
-        }
-        int r = k[0];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            r = i <= last_valid ? k[i] : r;                    // rows past the slide re-read the last valid one
-            const unsigned char* rowp = a.X + (xbase + r) * row_bytes;
-            static_assert(U == 1, "one KiB unit per row: see the launch-side comment");
-            asm_load16_s<0>(buf[i * U], voff, rowp);
-        }
-    };
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](const u32x4_t (&buf)[NL], const Tile& t) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            wave_lds_order();                                   // earlier fragment reads of this tile are done
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                tileA[i * 64 + (lane ^ i)] = __builtin_bit_cast(uint4, buf[i * U + u]);
-            wave_lds_order();
-            const int r = lane & 15;
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const uint4 av = tileA[r * 64 + ((kk * 4 + (lane >> 4)) ^ r)];
-                if constexpr (BF16) {
-                    const bf16x8_t A = __builtin_bit_cast(bf16x8_t, av);
-#pragma unroll
-                    for (int term = 0; term < 3; ++term)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, __builtin_bit_cast(bf16x8_t, bank[(u * 16 + kk) * 3 + term]), acc, 0, 0, 0);
-                } else {
-                    const u32x4_t bv = bank[u * 16 + kk];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av.x), __uint_as_float(bv[0]), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av.y), __uint_as_float(bv[1]), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av.z), __uint_as_float(bv[2]), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av.w), __uint_as_float(bv[3]), acc, 0, 0, 0);
-                }
-            }
-        }
-        wave_lds_order();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tile[((lane >> 4) * 4 + i) * LDT + (lane & 15)] = acc[i];
-        wave_lds_order();
-        if (lane < 16) row_epilogue(a, tile + lane * LDT, LDT, t.base, t.row0 + lane, t.row0 + lane < t.nk);
-        acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    };
-    int g = blockIdx.x * 4 + wave;
-    u32x4_t bufA[NL], bufB[NL];
-    Tile tA, tB;
-    if (g < total) issue(g, tA, bufA);
-    while (g < total) {
-        g += stride;
-        const bool moreB = g < total;
-        if (moreB) { issue(g, tB, bufB); asm_wait_keep<NL, NL>(bufA); }
-        else asm_wait_keep<0, NL>(bufA);
-        compute(bufA, tA);
-        if (!moreB) break;
-        g += stride;
-        const bool moreA = g < total;
-        if (moreA) { issue(g, tA, bufA); asm_wait_keep<NL, NL>(bufB); }
-        else asm_wait_keep<0, NL>(bufB);
-        compute(bufB, tB);
-    }
-}
-
 // Row statistics from a given logits matrix [N, Ct] (row-major): same columns as the score
 // pass writes.  One thread per row; used by the helpers that take logits, not bags.
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* logits, int64_t N, int Ct, int C,
@@ -797,34 +654,6 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
         const int resident = 256 * (smem <= 80 * 1024 ? 2 : 1);
         if (wgs > resident) wgs = resident;
         const int row_b = B->D * moc_elem_size(B->dtype);
-        // A/B switch: MOC_SCORES_VARIANT=rows selects the row-contiguous form.  Measured (scripts/
-        // bench_scores.py): both sustain 4.8-5.0 TB/s on 3 GB, the fragment-load form is faster on the
-        // 32-slide masked launch (5.1 vs 3.9 TB/s: 8 waves/CU and a cheaper start), so it is the default.
-        static const char* variant = getenv("MOC_SCORES_VARIANT");
-        // rows of exactly one KiB unit only: with two units per row the two 32-register tile buffers no
-        // longer fit beside the bank image, hipcc parks in-flight load destinations in AGPRs and the
-        // data arriving later lands in registers that have been re-used (tests/test_isa_hazards_cpu.py)
-        const bool rows_ok = row_b == 1024 && a.NT == 1 && !f16;
-        if (rows_ok && variant && variant[0] == 'r') {
-            const size_t smem2 = 4 * 16 * 1024 + 4 * 16 * 17 * sizeof(float) + (size_t)B->n_slides * 24 + 16;
-            MOC_REQUIRE(smem2 <= 160 * 1024, "moc_scores: n_slides=%d needs %zu B of LDS (> 160 KiB)", B->n_slides, smem2);
-            int wg2 = (int)((tiles + 3) / 4);
-            if (wg2 > 256) wg2 = 256;                                     // one workgroup (4 waves) per CU
-#define MOC_LAUNCH_ROWS(UU, BF)                                                                         \
-            do {                                                                                        \
-                static bool attr_set = false;                                                           \
-                if (!attr_set) {                                                                        \
-                    (void)hipFuncSetAttribute((const void*)scores_rows_kernel<UU, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                    attr_set = true;                                                                    \
-                }                                                                                       \
-                scores_rows_kernel<UU, BF><<<wg2, 256, smem2, s>>>(a, B->n_slides);                     \
-            } while (0)
-            if (bf) MOC_LAUNCH_ROWS(1, true);
-            else MOC_LAUNCH_ROWS(1, false);
-#undef MOC_LAUNCH_ROWS
-            MOC_CHECK_LAUNCH("moc_scores(rows)");
-            return MOC_OK;
-        }
 #define MOC_LAUNCH_STREAM(NF, BF, NTT, FH)                                                              \
         do {                                                                                            \
             static bool attr_set = false;                                                               \

@@ -167,7 +167,7 @@ class SlideBatch:
                 mixed=torch.empty((Cc, T), **f32), pooled=torch.empty((n, Cc), **f32),
                 topk_idx=torch.empty((n, Cc, K), **i32), topk_cnt=torch.empty((n, Cc), **i32),
                 loss=torch.empty(n, **f32), pred=torch.empty(n, **i32),
-                pair_dh=torch.empty((Cc * K, HIDDEN), **f32), pair_x=torch.empty((Cc * K, self.D), **f32),
+                pair_dh=torch.empty((Cc * K, HIDDEN), **f32),
                 W2_alt=torch.empty((4, HIDDEN), **f32),
                 pair_row=torch.empty(Cc * K, dtype=torch.int64, device=dev), n_pair=torch.zeros(1, **i32))
             self._ws = (t, MocMetaWs(**{k: ptr(v) for k, v in t.items()}))
