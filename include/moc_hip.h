@@ -65,7 +65,8 @@ typedef struct moc_batch {
                                   NULL = row_off (slides packed in batch order).  Lets a
                                   batch visit resident slides in any order / repeatedly
                                   (dataset_generic.py:380-393 repeat_num) without copies */
-    const uint8_t* mask;       /* device [total_rows] 0/1 keep flags, or NULL = keep all
+    const uint8_t* mask;       /* [total_rows] 0/1 keep flags in device OR device-mapped pinned host memory
+                                  (read once, by moc_mask_compact), or NULL = keep all
                                   (main_moc.py:329-331; drawn by the host, see moc_amd)  */
     int32_t        C;          /* n_classes                                              */
     int32_t        Ce;         /* columns of zeroshot_weights_ext (C + background)       */

@@ -330,7 +330,9 @@ def train_dp(model, loader, optimizer, device, args, group=None):
     # point the C ABI's gradient outputs at the flat buffer: the all-reduce is ONE collective
     for name, v in zip(("g_W1", "g_b1", "g_W2", "g_b2"), fg.views):
         setattr(meta.c, name, v.data_ptr())
-    batch.phase_a(bank)
+    resident = isinstance(loader, M.ResidentBags)
+    if not resident:
+        batch.phase_a(bank)                 # (a resident split's phase A is already issued, possibly a pass ahead)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     # the whole pass is ONE call, the host loop lives in C.  On one node the exchange happens inside
     # the step kernel (moc_train_steps_p2p: forward + step, two launches); otherwise per step
@@ -347,6 +349,8 @@ def train_dp(model, loader, optimizer, device, args, group=None):
         del keep
         train_dp.exchange = "collective"
     meta.advance(len(sizes))            # the optimizer's own step counters, once per pass
+    if resident:
+        M.resident_pass_done(loader, device, args)
     train_dp.last = (batch, lab, fg)
 
 

@@ -126,6 +126,17 @@ class SlideBatch:
         """New keep flags for the same visits (next epoch): async H2D into the resident mask array."""
         assert self.mask is not None and host_mask_u8.numel() == self.total and host_mask_u8.dtype == torch.uint8
         self.mask.copy_(host_mask_u8, non_blocking=True)
+        self.c.mask = ptr(self.mask)
+        self.kept_rows_host = int(kept_rows)
+
+    def use_host_mask(self, pinned_mask_u8: torch.Tensor, kept_rows: int):
+        """Keep flags read by the compaction kernel straight from PINNED host memory (device-mapped by
+        hipHostMalloc): no copy command at all.  Measured on the GPU box: the 480 KB asynchronous upload it
+        replaces blocked the issuing thread for ~7 ms once every few dozen epochs (scripts/diag_stall.py).
+        The caller keeps the buffer untouched until the pass that reads it has run."""
+        assert pinned_mask_u8.is_pinned() and pinned_mask_u8.numel() == self.total and pinned_mask_u8.dtype == torch.uint8
+        self._host_mask = pinned_mask_u8
+        self.c.mask = pinned_mask_u8.data_ptr()
         self.kept_rows_host = int(kept_rows)
 
     # ---- phase A ----
@@ -247,6 +258,20 @@ def draw_row_masks(total: int, out: torch.Tensor | None = None):
     m = torch.rand(total) > 0.5
     out.copy_(m)
     return out, int(m.sum())
+
+
+def draw_row_masks_from(rng_state: torch.Tensor, total: int, out: torch.Tensor):
+    """As draw_row_masks, but from the given generator state (a `torch.get_rng_state()` tensor), without
+    touching torch's generator: -> (out, kept rows, state after the draws).  When the state's layout is not
+    the one the library knows, torch itself draws from ITS generator and the third value is None."""
+    if torch.get_default_dtype() == torch.float32:
+        st = rng_state.clone()
+        kept = lib().moc_host_draw_masks(ptr(st), st.numel(), total, ptr(out))
+        if kept >= 0:
+            return out, int(kept), st
+    m = torch.rand(total) > 0.5
+    out.copy_(m)
+    return out, int(m.sum()), None
 
 
 def train_use_bits(discard) -> int:

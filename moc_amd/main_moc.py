@@ -22,6 +22,8 @@ How the loops map onto the GPU
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -128,12 +130,15 @@ class ResidentBags:
                 self._plans.clear()
             sizes = [self.sizes[k] for k in order]
             T = sum(sizes)
-            batch = SlideBatch(self.X, sizes, C_, Ce, topj, topk, discard, mask=torch.ones(T, dtype=torch.uint8),
-                               x_starts=[self.starts[k] for k in order])
+            # two sets of work arrays: while the meta-learner steps through epoch e on one, phase A of
+            # epoch e+1 (parameter-free) fills the other on a side stream (_resident_pass_setup)
+            batches = [SlideBatch(self.X, sizes, C_, Ce, topj, topk, discard, mask=torch.ones(T, dtype=torch.uint8),
+                                  x_starts=[self.starts[k] for k in order]) for _ in range(2)]
             lab = torch.tensor([self.labels[k] for k in order], dtype=torch.int64).to(self.X.device)
-            stage = [torch.empty(T, dtype=torch.uint8).pin_memory() for _ in range(3)]
-            plan = self._plans[key] = {"batch": batch, "labels": lab, "stage": stage,
-                                       "events": [None, None, None], "turn": 0}
+            stage = [torch.empty(T, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            plan = self._plans[key] = {"batch": batches[0], "batches": batches, "labels": lab, "stage": stage,
+                                       "stage_free": [None, None], "turn": 0, "ahead": None,
+                                       "side": torch.cuda.Stream(device=self.X.device)}
         return plan
 
     def eval_plan(self, C_, Ce, topj, topk, discard):
@@ -237,22 +242,81 @@ def slide_process(feat, zeroshot_weights, zeroshot_weights_ext,
     }
 
 
+PREFETCH_PHASE_A = os.environ.get("MOC_PREFETCH_PHASE_A", "1") != "0"
+
+
+def _issue_phase_a(plan, turn, bank, rng_before):
+    """Draw the masks that follow generator state `rng_before` (main_moc.py:330: same stream of bits),
+    upload them and run phase A into work-array set `turn` on the CURRENT stream.
+    -> generator state after the draws (None: the state's layout is unknown, torch drew and advanced itself)."""
+    batch = plan["batches"][turn]
+    if plan["stage_free"][turn] is not None:
+        plan["stage_free"][turn].synchronize()          # the phase A that read that pinned buffer has run
+    stage, kept, rng_after = engine.draw_row_masks_from(rng_before, batch.total, plan["stage"][turn])
+    batch.use_host_mask(stage, kept)                    # read in place by the compaction kernel: no upload
+    batch.phase_a(plan["bank"])
+    ev = torch.cuda.Event()
+    ev.record()
+    plan["stage_free"][turn] = ev                       # ... so the buffer is free again when phase A has run
+    return rng_after
+
+
 def _resident_pass_setup(res, device, args):
-    """Train pass over a resident split: nothing is copied or allocated per epoch except the new
-    mask bytes.  Returns (batch with this epoch's masks uploaded, device labels, bank)."""
+    """Train pass over a resident split: nothing is copied or allocated per epoch except the new mask
+    bytes.  Returns (batch with this epoch's phase A issued, device labels, bank).
+
+    Phase A has no trainable parameter, so the pass for epoch e+1 is issued one call AHEAD, on a side
+    stream, while the sequential meta-steps of epoch e occupy a fraction of the GPU (resident_pass_done).
+    It is speculative only in what the CPU generator will hold when train() is called again: the masks
+    are drawn from a COPY of the state, torch's generator is left where epoch e put it, and the next call
+    adopts the work only if it finds exactly that state (and the same bank); otherwise it is dropped and
+    phase A runs here, as before."""
     bank = _bank_for(res.X, device)
     assert bank.C == args.n_classes
     plan = res.train_plan(bank.C, bank.Ce, args.topj, args.topk, args.discard_classifiers)
-    batch, lab = plan["batch"], plan["labels"]
-    t = plan["turn"] = (plan["turn"] + 1) % len(plan["stage"])
-    if plan["events"][t] is not None:
-        plan["events"][t].synchronize()               # that staging buffer's last upload has finished
-    stage, kept = engine.draw_row_masks(batch.total, plan["stage"][t])   # main_moc.py:330, same stream of bits
-    batch.set_mask(stage, kept)
-    ev = torch.cuda.Event()
-    ev.record()
-    plan["events"][t] = ev
-    return batch, lab, bank
+    plan["bank"] = bank
+    lab = plan["labels"]
+    now = torch.get_rng_state()
+    ahead, plan["ahead"] = plan["ahead"], None
+    if ahead is not None and ahead["bank"] is bank and ahead["after"] is not None and torch.equal(ahead["before"], now):
+        torch.set_rng_state(ahead["after"])             # the draws happened: put the generator where they leave it
+        torch.cuda.current_stream().wait_event(ahead["done"])
+        plan["turn"] = ahead["turn"]
+    else:
+        if ahead is not None:
+            ahead["done"].synchronize()                 # dropped work still owns that set of arrays until it ends
+        plan["turn"] = 1 - plan["turn"]
+        after = _issue_phase_a(plan, plan["turn"], bank, now)
+        if after is not None:
+            torch.set_rng_state(after)
+    plan["batch"] = plan["batches"][plan["turn"]]
+    return plan["batch"], lab, bank
+
+
+def resident_pass_done(res, device, args):
+    """Call after the pass's meta-steps are issued: starts phase A of the NEXT pass on the side stream."""
+    if not PREFETCH_PHASE_A:
+        return
+    bank = _bank_for(res.X, device)
+    plan = res.train_plan(bank.C, bank.Ce, args.topj, args.topk, args.discard_classifiers)
+    turn, other = plan["turn"], 1 - plan["turn"]
+    main, side = torch.cuda.current_stream(), plan["side"]
+    # a set of arrays is free again when the meta-steps that read it have run: mark this pass's end on `main`;
+    # the other set was last read by the PREVIOUS pass's meta-steps (their mark was left one call ago), so the
+    # side stream waits for that one only and phase A of the next pass overlaps THIS pass's meta-steps
+    mark = torch.cuda.Event()
+    mark.record(main)
+    plan.setdefault("steps_done", [None, None])[turn] = mark
+    before = torch.get_rng_state()
+    with torch.cuda.stream(side):
+        if plan["steps_done"][other] is not None:
+            side.wait_event(plan["steps_done"][other])
+        after = _issue_phase_a(plan, other, bank, before)
+        done = torch.cuda.Event()
+        done.record(side)
+    if after is None:                                   # torch drew for us and moved its generator: undo, no speculation
+        torch.set_rng_state(before)
+    plan["ahead"] = {"turn": other, "before": before, "after": after, "done": done, "bank": bank}
 
 
 def train(model, train_loader, optimizer, device, args):
@@ -260,10 +324,10 @@ def train(model, train_loader, optimizer, device, args):
     model.train()
     use = engine.train_use_bits(args.discard_classifiers)
     if isinstance(train_loader, ResidentBags):
-        batch, lab, bank = _resident_pass_setup(train_loader, device, args)
+        batch, lab, bank = _resident_pass_setup(train_loader, device, args)      # phase A issued (or adopted)
         meta = MetaState(model, optimizer)
-        batch.phase_a(bank)
         engine.train_steps(batch, meta, lab, 0, batch.n_slides, use)
+        resident_pass_done(train_loader, device, args)
         train.last = (batch, lab)
         return
     X, sizes, x_starts, labels = _collect(train_loader, device, args)
