@@ -521,6 +521,132 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
     }
 }
 
+// ---- wide banks (16-bit storage, 4..8 n-tiles): K-split form --------------------------------------
+// The whole image no longer fits in LDS (C = 64, D = 1024: 5 x 96 KiB), and the generic kernel's answer --
+// one n-tile at a time, rows re-read per n-tile, image re-staged per 64 rows -- moves 9x the bag's bytes
+// through L2.  Here a workgroup owns 256 rows (a wave 4 row tiles) and keeps ALL their accumulators
+// (4 x NT tiles per wave, in AGPRs) while the contraction dimension goes by in chunks of 64 columns:
+// per chunk the image slice of every n-tile (NT x 6 KiB) and the workgroup's A fragments (32 KiB) arrive
+// by LDS-DMA into the other half of a double buffer while the matrix cores work on this half.  Every bag
+// row is read once; the image slice is read once per 256 rows and each B fragment feeds 4 MFMAs.  All LDS
+// reads of the loop are hand-issued with counted waits (an ordinary LDS read makes hipcc wait vmcnt(0)
+// first -- the DMA in flight writes LDS too -- which would serialise DMA and MFMA).
+constexpr int WD_R = 4;               // row tiles per wave
+constexpr int WD_KC = 2;              // k-steps (of 32 columns) per chunk
+
+template <int NT, bool F16>
+__global__ __launch_bounds__(256, 1) void scores_wide_kernel(ScoresArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int B_BYTES = NT * WD_KC * 3 * 1024;                  // image slice of one chunk
+    constexpr int A_BYTES = 4 * WD_R * WD_KC * 1024;                // 4 waves x R row tiles x KC k-steps x 1 KiB
+    constexpr int BUF = B_BYTES + A_BYTES;
+    constexpr int LDT = NT * 16 + 1;
+    float* tile = reinterpret_cast<float*>(smem + 2 * BUF) + (threadIdx.x >> 6) * 16 * LDT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int64_t base = a.row_off[b];
+    const int64_t xbase = a.x_off ? a.x_off[b] : base;
+    const int n = (int)(a.row_off[b + 1] - base);
+    const int nk = a.kept ? a.n_kept[b] : n;
+    const int wg_row0 = blockIdx.x * (4 * WD_R * 16);
+    if (wg_row0 >= nk) return;
+    const int64_t row_bytes = (int64_t)a.D * 2;
+    const int KK = a.D / 32, nchunk = KK / WD_KC;
+    const int img_bytes = KK * 3 * 1024;                            // one n-tile of the image
+
+    const unsigned char* rp[WD_R];                                  // this lane's row in each of the wave's row tiles
+#pragma unroll
+    for (int r = 0; r < WD_R; ++r) {
+        int slot = wg_row0 + (wave * WD_R + r) * 16 + (lane & 15);
+        slot = slot < nk ? slot : nk - 1;                           // clamp: loads stay in bounds
+        const int row = a.kept ? a.kept[base + slot] : slot;
+        rp[r] = a.X + (xbase + row) * row_bytes + (lane >> 4) * 16;
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto issue_chunk = [&](int c, int buf) {
+        unsigned char* dst = smem + buf * BUF;
+        // image: NT * KC * 3 pieces of 1 KiB, dealt round-robin to the 4 waves
+#pragma unroll
+        for (int i = 0; i < (NT * WD_KC * 3 + 3) / 4; ++i) {
+            const int piece = i * 4 + wave;                          // [nt][kl][term]
+            if (piece < NT * WD_KC * 3) {
+                const int nt = piece / (WD_KC * 3), rest = piece - nt * (WD_KC * 3);
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.bank + (int64_t)nt * img_bytes + ((int64_t)c * WD_KC * 3 + rest) * 1024 + lane * 16),
+                                                 (lptr_t)(dst + piece * 1024), 16, 0, 0);
+            }
+        }
+        // A fragments of this wave: [r][kl] pieces of 1 KiB
+#pragma unroll
+        for (int r = 0; r < WD_R; ++r)
+#pragma unroll
+            for (int kl = 0; kl < WD_KC; ++kl)
+                __builtin_amdgcn_global_load_lds((gptr_t)(rp[r] + ((int64_t)c * WD_KC + kl) * 64),
+                                                 (lptr_t)(dst + B_BYTES + ((wave * WD_R + r) * WD_KC + kl) * 1024), 16, 0, 0);
+    };
+
+    f32x4_t acc[WD_R * NT];
+#pragma unroll
+    for (int q = 0; q < WD_R * NT; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    issue_chunk(0, 0);
+    __syncthreads();                                                // (its fence waits for the DMA: vmcnt(0))
+    for (int c = 0; c < nchunk; ++c) {
+        if (c + 1 < nchunk) issue_chunk(c + 1, (c + 1) & 1);
+        const unsigned buf = (unsigned)(uintptr_t)(smem + (c & 1) * BUF);
+        const unsigned b_base = buf + lane * 16;
+        const unsigned a_base = buf + B_BYTES + wave * WD_R * WD_KC * 1024 + lane * 16;
+        // steps s = (kl, term); B fragments of step s+1 and (at term 0) the A fragments of its k-step are
+        // requested before the MFMAs of step s
+        u32x4_t A[2][WD_R], Bf[2][NT];
+#pragma unroll
+        for (int r = 0; r < WD_R; ++r) asm_lds16<0>(A[0][r], a_base + (r * WD_KC + 0) * 1024);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm_lds16<0>(Bf[0][nt], b_base + ((nt * WD_KC + 0) * 3 + 0) * 1024);
+#pragma unroll
+        for (int s2 = 0; s2 < WD_KC * 3; ++s2) {
+            const int kl = s2 / 3, term = s2 % 3, cur = s2 & 1, nxt = cur ^ 1;
+            const int kl_n = (s2 + 1) / 3, term_n = (s2 + 1) % 3;
+            int pending = 0;
+            if (s2 + 1 < WD_KC * 3) {
+                if (term_n == 0) {
+#pragma unroll
+                    for (int r = 0; r < WD_R; ++r) asm_lds16<0>(A[kl_n & 1][r], a_base + (r * WD_KC + kl_n) * 1024);
+                    pending += WD_R;
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) asm_lds16<0>(Bf[nxt][nt], b_base + ((nt * WD_KC + kl_n) * 3 + term_n) * 1024);
+                pending += NT;
+            }
+            // wait for everything older than the `pending` reads just issued
+            if (pending == NT + WD_R) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT + WD_R) : "memory");
+            else if (pending == NT) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm_touch<0, NT>(Bf[cur]);
+            if (term == 0) asm_touch<0, WD_R>(A[kl & 1]);
+#pragma unroll
+            for (int r = 0; r < WD_R; ++r)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[r * NT + nt] = moc_mfma_half<F16>(A[kl & 1][r], Bf[cur][nt], acc[r * NT + nt]);
+        }
+        __syncthreads();                                            // next chunk landed and visible; this half free
+    }
+    // ---- epilogue: one row tile at a time through the wave's LDS tile
+#pragma unroll
+    for (int r = 0; r < WD_R; ++r) {
+        const int row0 = wg_row0 + (wave * WD_R + r) * 16;
+        if (row0 >= nk) break;                                      // wave-uniform
+        wave_lds_order();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tile[((lane >> 4) * 4 + i) * LDT + nt * 16 + (lane & 15)] = acc[r * NT + nt][i] * a.oscale;
+        wave_lds_order();
+        row_epilogue_wide<NT>(a, tile, base, row0, nk);
+    }
+}
+
 // Row statistics from a given logits matrix [N, Ct] (row-major): same columns as the score
 // pass writes.  One thread per row; used by the helpers that take logits, not bags.
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* logits, int64_t N, int Ct, int C,
@@ -686,6 +812,35 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
 #undef MOC_LAUNCH_STREAM_NT
 #undef MOC_LAUNCH_STREAM
         return MOC_OK;
+    }
+    // wide banks on 16-bit storage: the K-split form (every bag row read once)
+    if (bf && a.NT >= 4 && a.NT <= 8 && B->D % 64 == 0) {
+        const size_t buf = (size_t)a.NT * WD_KC * 3 * 1024 + (size_t)4 * WD_R * WD_KC * 1024;
+        const size_t smem_w = 2 * buf + (size_t)4 * 16 * (a.NT * 16 + 1) * sizeof(float);
+        dim3 grid_w(moc_cdiv(B->max_rows, 4 * WD_R * 16), B->n_slides);
+#define MOC_LAUNCH_WIDE(NTT)                                                                            \
+        do {                                                                                            \
+            static bool attr_set[2] = {false, false};                                                   \
+            if (!attr_set[f16]) {                                                                       \
+                if (f16) (void)hipFuncSetAttribute((const void*)scores_wide_kernel<NTT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                else (void)hipFuncSetAttribute((const void*)scores_wide_kernel<NTT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                attr_set[f16] = true;                                                                   \
+            }                                                                                           \
+            if (f16) scores_wide_kernel<NTT, true><<<grid_w, 256, smem_w, s>>>(a);                      \
+            else scores_wide_kernel<NTT, false><<<grid_w, 256, smem_w, s>>>(a);                         \
+        } while (0)
+        if (smem_w <= 160 * 1024) {
+            switch (a.NT) {
+                case 4: MOC_LAUNCH_WIDE(4); break;
+                case 5: MOC_LAUNCH_WIDE(5); break;
+                case 6: MOC_LAUNCH_WIDE(6); break;
+                case 7: MOC_LAUNCH_WIDE(7); break;
+                default: MOC_LAUNCH_WIDE(8); break;
+            }
+            MOC_CHECK_LAUNCH("moc_scores(wide)");
+            return MOC_OK;
+        }
+#undef MOC_LAUNCH_WIDE
     }
     a.tpw = 1;
     const size_t smem = img + (size_t)4 * 16 * (a.NT * 16 + 1) * sizeof(float);

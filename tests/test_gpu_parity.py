@@ -37,7 +37,8 @@ def _engine():
 # ------------------------------------------------------------------ score pass
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,C,D", [(1, 2, 512), (17, 2, 512), (1000, 3, 512), (4099, 30, 512), (700, 64, 1024), (333, 2, 256),
-                                   (2500, 20, 512), (1500, 50, 512), (900, 13, 256), (1100, 30, 1024)])
+                                   (2500, 20, 512), (1500, 50, 512), (900, 13, 256), (1100, 30, 1024),
+                                   (3001, 64, 1024), (1100, 100, 512), (530, 124, 256), (260, 80, 768)])
 def test_scores_and_row_stats_match_oracle(dev, dtype, N, C, D):
     E = _engine()
     W, We = synth.make_bank(100 + N, D, C)
