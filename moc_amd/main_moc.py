@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -348,6 +349,45 @@ def train(model, train_loader, optimizer, device, args):
         train.last = (batch, lab)    # keeps the buffers alive until the stream has drained; also for tests
 
 
+def _binary_auc(pos: np.ndarray, score: np.ndarray) -> float:
+    """Area under the ROC curve of `score` for the boolean labels `pos`: the Mann-Whitney statistic with
+    mid-ranks for ties, which is what the trapezoid over sklearn's roc_curve thresholds adds up to."""
+    order = np.argsort(score, kind="mergesort")
+    s = score[order]
+    # mid-rank of every tie group: first occurrence index + (group size - 1) / 2, 1-based
+    start = np.r_[True, s[1:] != s[:-1]]
+    first = np.flatnonzero(start)
+    size = np.diff(np.r_[first, s.size])
+    mid = np.repeat(first + (size - 1) / 2.0 + 1.0, size)
+    n_pos = int(pos.sum())
+    n_neg = pos.size - n_pos
+    return float((mid[pos[order]].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * n_neg))
+
+
+def _auc(y_true: np.ndarray, y_score: np.ndarray) -> float:
+    """roc_auc_score(y, p[:, 1]) for two classes, roc_auc_score(y, p, multi_class='ovo', average='macro')
+    otherwise (main_moc.py:507-514), computed directly: sklearn's input validation and per-pair Python
+    machinery cost 0.4 ms per binary call and 0.1-0.6 s per call at 30-64 classes -- more than the GPU
+    side of the whole evaluation.  Anything sklearn would reject (a class missing from y_true, ...) is
+    handed to sklearn so that the same exception comes out."""
+    classes = np.unique(y_true)
+    if y_score.ndim == 1:
+        if classes.size != 2:
+            return roc_auc_score(y_true, y_score)
+        return _binary_auc(y_true == classes[1], y_score)
+    if classes.size != y_score.shape[1] or classes.size < 2 or not np.array_equal(classes, np.arange(classes.size)):
+        return roc_auc_score(y_true, y_score, multi_class="ovo", average="macro")
+    masks = [y_true == c for c in classes]
+    total, n_pairs = 0.0, 0
+    for a in range(classes.size):
+        for b in range(a + 1, classes.size):
+            ab = masks[a] | masks[b]
+            a_true = masks[a][ab]
+            total += (_binary_auc(a_true, y_score[ab, a]) + _binary_auc(~a_true, y_score[ab, b])) / 2.0
+            n_pairs += 1
+    return total / n_pairs
+
+
 def _metrics(pooled_cpu, labels, losses, n_div, real_len, args):
     """The shared tail of the three evaluation loops (main_moc.py:439-460, :501-520)."""
     test_loss = 0
@@ -361,14 +401,8 @@ def _metrics(pooled_cpu, labels, losses, n_div, real_len, args):
     else:
         raise NotImplementedError
     probs = F.softmax(pooled_cpu * temperature, dim=1)
-    n_classes = probs.shape[1]
-    if n_classes == 2:
-        class_probs = probs[:, 1]
-        roc_kwargs = {}
-    else:
-        class_probs = probs
-        roc_kwargs = {'multi_class': 'ovo', 'average': 'macro'}
-    auc = roc_auc_score(lbl_all.numpy(), class_probs.numpy(), **roc_kwargs)
+    class_probs = probs[:, 1] if probs.shape[1] == 2 else probs
+    auc = _auc(lbl_all.numpy(), class_probs.numpy())
     return {"loss": test_loss, "acc": correct / real_len, "auc": auc}
 
 

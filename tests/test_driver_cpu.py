@@ -102,3 +102,42 @@ def test_cli_flags_match_reference_defaults():
     assert a.discard_classifiers == [] and a.ablation_study == "none" and a.check_zeroshot is True and not a.summary
     a = run_moc.get_args("--fold 3 --shot 8 --topj 400 --dataset rcc --discard_classifiers topk bottomk --disable_tqdm".split())
     assert a.fold == 3 and a.topj == 400 and a.dataset == "rcc" and a.discard_classifiers == ["topk", "bottomk"] and a.disable_tqdm
+
+
+def test_direct_auc_equals_sklearn():
+    """main_moc._auc replaces roc_auc_score on the evaluation path: same numbers, ties included."""
+    import numpy as np
+    import pytest
+    from sklearn.metrics import roc_auc_score
+    from moc_amd.main_moc import _auc
+    rng = np.random.default_rng(3)
+    for n in (2, 7, 202, 1000):
+        y = rng.integers(0, 2, n)
+        y[0], y[1] = 0, 1
+        p = rng.random(n)
+        assert abs(_auc(y, p) - roc_auc_score(y, p)) < 1e-12
+        pq = np.round(p, 1)                                   # heavy ties
+        assert abs(_auc(y, pq) - roc_auc_score(y, pq)) < 1e-12
+    for C in (3, 5, 30):
+        n = 40 * C
+        y = rng.integers(0, C, n)
+        y[:C] = np.arange(C)
+        logits = rng.standard_normal((n, C)) + 1.5 * np.eye(C)[y]
+        logits = np.round(logits, 1)                          # ties across rows
+        p = np.exp(logits) / np.exp(logits).sum(1, keepdims=True)
+        ref = roc_auc_score(y, p, multi_class="ovo", average="macro")
+        assert abs(_auc(y, p) - ref) < 1e-12
+    # inputs sklearn rejects (or answers with NaN + a warning, depending on its version) get sklearn's answer
+    import warnings
+    for y, p, kw in ((np.zeros(5, dtype=np.int64), np.linspace(0, 1, 5), {}),
+                     (np.array([0, 1, 1, 0]), np.full((4, 3), 1 / 3), dict(multi_class="ovo", average="macro"))):
+        def run(f, *a, **k):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                try:
+                    return ("value", f(*a, **k))
+                except ValueError as e:
+                    return ("error", str(e))
+        mine, theirs = run(_auc, y, p), run(roc_auc_score, y, p, **kw)
+        assert mine[0] == theirs[0]
+        assert mine[1] == theirs[1] or (isinstance(mine[1], float) and np.isnan(mine[1]) and np.isnan(theirs[1]))
