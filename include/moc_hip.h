@@ -179,7 +179,8 @@ int moc_phase_a(const moc_batch_t* B, const void* bank, moc_stream_t stream);
  * train: ~discard_bits & 15 (main_moc.py:396-403); eval: see moc_amd.main_moc
  * for the reference's quirk (main_moc.py:486-492). */
 
-/* a10-a11 for slides [slide0, slide0+n): H1, gates, mixed */
+/* a10-a11 for slides [slide0, slide0+n): H1, gates, mixed.  ws->H1 / ws->gates may be NULL (evaluation:
+ * only the backward pass reads them; 256 + 16 bytes per selected row not written). */
 int moc_meta_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
                      int slide0, int n, uint32_t use_bits, moc_stream_t stream);
 

@@ -215,9 +215,11 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
         W2s[threadIdx.x] = w2_pre;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 16 * H; e += 256) {
-        const int r = e >> 6, h = e & 63;
-        if (row0 + r < S) a.H1[(base + row0 + r) * H + h] = Hs[r][h];
+    if (a.H1) {                          // needed by the backward pass only: evaluation passes NULL
+        for (int e = threadIdx.x; e < 16 * H; e += 256) {
+            const int r = e >> 6, h = e & 63;
+            if (row0 + r < S) a.H1[(base + row0 + r) * H + h] = Hs[r][h];
+        }
     }
     if (threadIdx.x < 64) {
         const int r = threadIdx.x >> 2, i = threadIdx.x & 3;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
         z += b2_pre;
         const float g = 1.f / (1.f + expf(-z));
         Gs[r][i] = g;
-        if (row0 + r < S) a.gates[(base + row0 + r) * 4 + i] = g;
+        if (a.gates && row0 + r < S) a.gates[(base + row0 + r) * 4 + i] = g;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 16 * C; e += 256) {
@@ -1088,12 +1090,12 @@ AdamCoef adam_coef(const moc_meta_t* M, int64_t step, float grad_scale) {
 }
 
 int check_meta(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const char* who,
-               bool need_adam, bool need_grad) {
+               bool need_adam, bool need_grad, bool need_h1 = true) {
     MOC_REQUIRE(M && ws, "%s: null meta/ws", who);
     MOC_REQUIRE(M->H == H, "%s: hidden width %d unsupported (must be %d)", who, M->H, H);
     MOC_REQUIRE(M->D == B->D, "%s: meta D=%d != batch D=%d", who, M->D, B->D);
     MOC_REQUIRE(M->W1 && M->b1 && M->W2 && M->b2, "%s: null parameter", who);
-    MOC_REQUIRE(ws->H1 && ws->gates && ws->mixed && ws->pooled && ws->topk_idx && ws->topk_cnt && ws->loss && ws->pred,
+    MOC_REQUIRE((!need_h1 || (ws->H1 && ws->gates)) && ws->mixed && ws->pooled && ws->topk_idx && ws->topk_cnt && ws->loss && ws->pred,
                 "%s: null work array", who);
     MOC_REQUIRE(B->sel_row && B->n_sel && B->cand, "%s: batch has no phase-A outputs", who);
     MOC_REQUIRE(B->topk <= 256 && B->C <= 256, "%s: topk/C too large for the fused step (<= 256)", who);
@@ -1277,7 +1279,7 @@ int launch_w1(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws
 extern "C" int moc_meta_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
                                 int slide0, int n, uint32_t use_bits, moc_stream_t stream) {
     if (int rc = moc_check_batch(B, "moc_meta_forward")) return rc;
-    if (int rc = check_meta(B, M, ws, "moc_meta_forward", false, false)) return rc;
+    if (int rc = check_meta(B, M, ws, "moc_meta_forward", false, false, false)) return rc;
     MOC_REQUIRE(slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_meta_forward: bad slide range");
     // the parameters may have changed since the image was last written: rebuild it (H*D elements)
     if (int rc = launch_w1_image(B, M, (hipStream_t)stream)) return rc;

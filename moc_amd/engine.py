@@ -284,8 +284,13 @@ def eval_use_bits(discard) -> int:
     return 1 | (0 if "delta_softmax" in d else 2) | (0 if "delta_diff" in d else 4) | (0 if "delta_bottomk" in d else 8)
 
 
-def meta_forward(batch: SlideBatch, meta: MetaState, slide0: int, n: int, use_bits: int):
+def meta_forward(batch: SlideBatch, meta: MetaState, slide0: int, n: int, use_bits: int, keep_hidden: bool = True):
+    """keep_hidden=False (evaluation): H1 and the gates are not written -- only the backward pass reads them."""
     _, ws = batch.meta_ws()
+    if not keep_hidden:
+        ws = type(ws).from_buffer_copy(ws)
+        ws.H1 = None
+        ws.gates = None
     check(lib().moc_meta_forward(C.byref(batch.c), C.byref(meta.c), C.byref(ws), slide0, n, use_bits, _stream()),
           "moc_meta_forward")
 

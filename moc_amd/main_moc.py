@@ -449,7 +449,7 @@ def _eval_pass(loader, device, args, mode, model=None, pooling_func=None):
         else:
             batch.phase_a(bank)
             if mode == "eval":
-                engine.meta_forward(batch, meta, 0, n, engine.eval_use_bits(args.discard_classifiers))
+                engine.meta_forward(batch, meta, 0, n, engine.eval_use_bits(args.discard_classifiers), keep_hidden=False)
             else:
                 engine.mix_fixed(batch, 0, n, args.ablation_study)
             engine.pool_loss(batch, lab, 0, n)
