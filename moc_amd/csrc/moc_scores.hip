@@ -794,17 +794,18 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
             if (a.NT == 1) MOC_LAUNCH_STREAM(NF, BF, 1, FH);                                            \
             else if (a.NT == 2) MOC_LAUNCH_STREAM(NF, BF, 2, FH);                                       \
             else if (a.NT == 3) MOC_LAUNCH_STREAM(NF, BF, 3, FH);                                       \
-            else if constexpr (!BF) MOC_LAUNCH_STREAM(NF, BF, 4, FH);                                   \
         } while (0)
         for (int s0 = 0; s0 < B->n_slides; s0 += chunk) {
             const int ns = B->n_slides - s0 < chunk ? B->n_slides - s0 : chunk;
             if (row_b % 1024 == 0) {
                 if (f16) MOC_LAUNCH_STREAM_NT(16, true, true);
                 else if (bf) MOC_LAUNCH_STREAM_NT(16, true, false);
+                else if (a.NT == 4) MOC_LAUNCH_STREAM(16, false, 4, false);      // fp32 only: four n-tiles
                 else MOC_LAUNCH_STREAM_NT(16, false, false);
             } else {
                 if (f16) MOC_LAUNCH_STREAM_NT(8, true, true);
                 else if (bf) MOC_LAUNCH_STREAM_NT(8, true, false);
+                else if (a.NT == 4) MOC_LAUNCH_STREAM(8, false, 4, false);
                 else MOC_LAUNCH_STREAM_NT(8, false, false);
             }
             MOC_CHECK_LAUNCH("moc_scores(stream)");
