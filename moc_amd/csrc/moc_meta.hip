@@ -467,6 +467,10 @@ struct PoolLds {
 // Pooling + loss of slide b by ONE workgroup of 16 waves (all threads must call): leaves the pooled
 // rows in L.topk_s, the pooled logits in L.pooled_s and (train) d loss/d pooled in L.dpool; returns
 // k = rows pooled per class.  `write_out`: this workgroup also publishes pooled/topk/loss/pred.
+// VPT = scores per thread per class (S <= 1024 * VPT); CE_OFF = widest xor offset of the cross-entropy
+// reduction (8: C <= 16 on lanes 0..15; 32: C <= 64 on the whole wave).
+// CG = classes handled per round (CG * VPT 64-bit keys live in registers).
+template <int VPT = PS_VPT, int CE_OFF = 8, int CG = 4>
 __device__ __forceinline__ int pool_phase(const FinishArgs& a, int b, const PoolLds& L, int PS_CAP, bool write_out,
                                           float* pooled_out, int32_t* topk_idx_out, int32_t* topk_cnt_out,
                                           int64_t* base_out) {
@@ -488,33 +492,33 @@ __device__ __forceinline__ int pool_phase(const FinishArgs& a, int b, const Pool
     // candidate: S <= 64*15 then, which the list holds.
     const int S = a.n_sel[b];
     const int k = K < S ? K : S;
-    for (int c0 = 0; c0 < C; c0 += 4) {
-        unsigned long long key[4][PS_VPT];
+    for (int c0 = 0; c0 < C; c0 += CG) {
+        unsigned long long key[CG][VPT];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
+        for (int cc = 0; cc < CG; ++cc) {
 #pragma unroll
-            for (int q = 0; q < PS_VPT; ++q) key[cc][q] = 0ull;
+            for (int q = 0; q < VPT; ++q) key[cc][q] = 0ull;
             if (c0 + cc < C) {                                   // uniform: no work for absent classes
                 const float* col = a.mixed_in + (int64_t)(c0 + cc) * a.stride + base;
-                float v[PS_VPT];
+                float v[VPT];
 #pragma unroll
-                for (int q = 0; q < PS_VPT; ++q) {
+                for (int q = 0; q < VPT; ++q) {
                     const int i = q * 1024 + (int)threadIdx.x;
                     v[q] = col[i < seg ? i : seg - 1];
                 }
 #pragma unroll
-                for (int q = 0; q < PS_VPT; ++q) {
+                for (int q = 0; q < VPT; ++q) {
                     const int i = q * 1024 + (int)threadIdx.x;
                     key[cc][q] = i < S ? ((unsigned long long)moc_key_desc(v[q]) << 32) | (unsigned)(~(unsigned)i) : 0ull;
                 }
             }
         }
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
+        for (int cc = 0; cc < CG; ++cc) {
             if (c0 + cc < C) {
                 unsigned long long m = 0;
 #pragma unroll
-                for (int q = 0; q < PS_VPT; ++q) m = key[cc][q] > m ? key[cc][q] : m;
+                for (int q = 0; q < VPT; ++q) m = key[cc][q] > m ? key[cc][q] : m;
                 m = wave_max_u64(m);
                 if (lane == 0) wmax[(c0 + cc) * 16 + wave] = m;
             }
@@ -523,7 +527,7 @@ __device__ __forceinline__ int pool_phase(const FinishArgs& a, int b, const Pool
         MOC_STAMP(11);
         // threshold = K-th largest wave maximum (keys are unique; 0 = empty wave), then candidates
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
+        for (int cc = 0; cc < CG; ++cc) {
             const int c = c0 + cc;
             if (c >= C) break;
             const unsigned long long mine = wmax[c * 16 + (lane & 15)];
@@ -539,7 +543,7 @@ __device__ __forceinline__ int pool_phase(const FinishArgs& a, int b, const Pool
                 T0 = ((unsigned long long)hi << 32) | lo;
             }
 #pragma unroll
-            for (int q = 0; q < PS_VPT; ++q) {
+            for (int q = 0; q < VPT; ++q) {
                 const unsigned long long v = key[cc][q];
                 if (v != 0ull && v >= T0) {
                     const int pos = atomicAdd(&ncand[c], 1);
@@ -614,14 +618,14 @@ __device__ __forceinline__ int pool_phase(const FinishArgs& a, int b, const Pool
         const float xv = lane < C ? pooled_s[lane] : -INFINITY;
         float mx = xv;
         int arg = lane < C ? lane : 0x7fffffff;
-        for (int off = 8; off > 0; off >>= 1) {        // lanes 0..15 hold the classes
+        for (int off = CE_OFF; off > 0; off >>= 1) {   // lanes 0..2*CE_OFF-1 hold the classes
             const float om = __shfl_xor(mx, off, 64);
             const int oa = __shfl_xor(arg, off, 64);
             if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
         }
         const float ex = lane < C ? expf(xv - mx) : 0.f;
         float se = ex;
-        for (int off = 8; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
+        for (int off = CE_OFF; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
         const float lse = mx + logf(se);
         if (lane < C && a.train) dpool[lane] = expf(xv - lse) - (lane == y ? 1.f : 0.f);
         if (lane == 0 && write_out) {
@@ -964,6 +968,194 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
     MOC_STAMP(18);
 }
 
+// ------------------------------------------------------------------ one-launch step, wide shapes
+// C <= 64, K <= 16, S <= 8192 (EBRAINS-30, the 64-way stress shape): hundreds of gradient pairs, whose bag
+// rows (P x D) and hidden activations (P x 64) do not fit in LDS.  Same grid as pool_w1_step_kernel (16
+// workgroups of 1024 threads, every one repeats the pooling), different split of the backward pass:
+// workgroup g owns the D/16 COLUMNS [g*D/16, ...) of W1 for all 64 hidden units, so it needs only a
+// D/16-wide piece of every pair's row (64 B at D = 512 bf16: one gather round, P x 64 B of LDS), and
+// instead of dh[P][64] it keeps per pair the four gate derivatives dz[p][0..3] and the 64-bit ReLU mask of
+// its hidden row: dh[p][h] = mask_p[h] ? sum_i dz[p][i] W2[i][h] : 0 is re-formed on the fly.  The small
+// tensors are split by hidden unit: workgroup g also owns W2[:, 4g..4g+3] and b1[4g..4g+3] (16 wave-wide
+// reductions over the pairs), workgroup 0 b2.
+struct WideLds {
+    unsigned char* region;      // candidate lists during pooling, then the pairs' row pieces
+    float *dz, *h1o;            // [P][4] gate derivatives, [P][4] H1 of this workgroup's four hidden units
+    unsigned* mask;             // [P][2] ReLU mask of the pair's hidden row
+    int* sidx;                  // [P]
+    int64_t* prow;              // [P]
+    float* W2s;                 // [4][H]
+    float* red;                 // [16 + 4 + 4] reduced small gradients
+};
+
+__global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, float* pooled_out, int32_t* topk_idx_out,
+                                                                 int32_t* topk_cnt_out, int PS_CAP, int region_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FinishArgs& a = g.f;
+    const int b = a.slide0, C = a.C, K = a.K, D = a.D;
+    const int wg = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int DS = D / 16, d_lo = wg * DS;               // this workgroup's columns of W1
+    const int esz = a.xdt == MOC_F32 ? 4 : 2;
+    const int PMAX = C * K;
+    // ---- LDS carve
+    unsigned char* region = smem;                                                    // [C][PS_CAP] u64  |  [P][DS] raw
+    unsigned long long* list = reinterpret_cast<unsigned long long*>(region);
+    unsigned long long* wmax = reinterpret_cast<unsigned long long*>(smem + region_bytes);   // [C][16]
+    float* pooled_s = reinterpret_cast<float*>(wmax + (size_t)C * 16);
+    float* dpool = pooled_s + C;
+    int* ncand = reinterpret_cast<int*>(dpool + C);
+    int* topk_s = ncand + C;                                                         // [C][K]
+    float* dz = reinterpret_cast<float*>(topk_s + PMAX);                             // [P][4]
+    float* h1o = dz + (size_t)PMAX * 4;                                              // [P][4]
+    unsigned* mask = reinterpret_cast<unsigned*>(h1o + (size_t)PMAX * 4);            // [P][2]
+    int* sidx_s = reinterpret_cast<int*>(mask + (size_t)PMAX * 2);                   // [P]
+    float* W2s = reinterpret_cast<float*>(sidx_s + PMAX);                            // [4][H]
+    float* red = W2s + 4 * H;                                                        // [32]
+    int64_t* prow_s = reinterpret_cast<int64_t*>((reinterpret_cast<uintptr_t>(red + 32) + 7) & ~(uintptr_t)7);   // [P]
+
+    // ---- operands that do not depend on this slide: requested first, consumed last.
+    // thread t owns hidden unit h = t >> 4 and columns d_lo + (t & 15) + 16 j, j < DS / 16 (DS = 32 or 64)
+    const int h_own = t >> 4, c_own = t & 15, NJ = DS / 16;
+    float pw[4], pm[4], pv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        pw[j] = pm[j] = pv[j] = 0.f;
+        if (j < NJ && a.apply_adam) {
+            const int e = h_own * D + d_lo + c_own + 16 * j;
+            pw[j] = g.W1[e]; pm[j] = g.m_W1[e]; pv[j] = g.v_W1[e];
+        }
+    }
+    if (t < 4 * H) W2s[t] = a.W2[t];
+    // small tensors: threads 0..15 -> W2[i][4 wg + jj] (i = t >> 2, jj = t & 3); 16..19 -> b1[4 wg + jj]; 20..23 -> b2 (wg 0)
+    float pS = 0.f, pSm = 0.f, pSv = 0.f;
+    int small = -1;                                       // flat tail index (b1 | W2 | b2), as in the narrow kernel
+    if (t < 16) small = H + (t >> 2) * H + wg * 4 + (t & 3);
+    else if (t < 20) small = wg * 4 + (t - 16);
+    else if (t < 24 && wg == 0) small = H + 4 * H + (t - 20);
+    if (small >= 0 && a.apply_adam) {
+        if (small >= 5 * H) { pS = a.b2[small - 5 * H]; pSm = a.m_b2[small - 5 * H]; pSv = a.v_b2[small - 5 * H]; }
+        else if (small >= H) { pS = a.W2[small - H]; pSm = a.m_W2[small - H]; pSv = a.v_W2[small - H]; }
+        else { pS = a.b1[small]; pSm = a.m_b1[small]; pSv = a.v_b1[small]; }
+    }
+    int64_t base;
+    const PoolLds L = {list, wmax, pooled_s, dpool, ncand, topk_s};
+    const int k = pool_phase<8, 32, 2>(a, b, L, PS_CAP, wg == 0, pooled_out, topk_idx_out, topk_cnt_out, &base);
+    __syncthreads();
+    // ---- pairs
+    const int P = C * k;
+    for (int p = t; p < P; p += 1024) {
+        const int c = p / k, sidx = topk_s[c * K + (p - c * k)];
+        sidx_s[p] = sidx;
+        mask[2 * p] = 0u; mask[2 * p + 1] = 0u;
+        prow_s[p] = a.sel_row[base + sidx];
+        const float* cd = a.cand + base + sidx;
+        const float sc[4] = {cd[(int64_t)c * a.stride], cd[(int64_t)(C + c) * a.stride],
+                             cd[(int64_t)(2 * C) * a.stride], cd[(int64_t)(2 * C + 1) * a.stride]};
+        const float4 lam = *reinterpret_cast<const float4*>(a.gates + (base + sidx) * 4);
+        const float lv[4] = {lam.x, lam.y, lam.z, lam.w};
+        const float gk = dpool[c] / (float)k;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            dz[p * 4 + i] = (a.use_bits >> i & 1u) ? gk * sc[i] * lv[i] * (1.f - lv[i]) : 0.f;
+    }
+    __syncthreads();
+    // hidden rows of the pairs: ReLU mask (64 bits) and the four values this workgroup owns
+    for (int e = t; e < P * 16; e += 1024) {
+        const int p = e >> 4, v = e & 15;
+        const float4 hv = *reinterpret_cast<const float4*>(a.H1 + (base + sidx_s[p]) * H + v * 4);
+        const unsigned bits = (hv.x > 0.f ? 1u : 0u) | (hv.y > 0.f ? 2u : 0u) | (hv.z > 0.f ? 4u : 0u) | (hv.w > 0.f ? 8u : 0u);
+        if (bits) atomicOr(&mask[2 * p + (v >> 3)], bits << ((v & 7) * 4));
+        if (v == wg) *reinterpret_cast<float4*>(h1o + p * 4) = hv;
+    }
+    // this workgroup's piece of every pair's bag row, as stored (DS * esz bytes, 16-B pieces)
+    {
+        const int ppr = DS * esz / 16;                     // pieces per pair
+        for (int e = t; e < P * ppr; e += 1024) {
+            const int p = e / ppr, v = e - p * ppr;
+            *reinterpret_cast<uint4*>(region + ((size_t)p * ppr + v) * 16) =
+                *reinterpret_cast<const uint4*>(a.X + (prow_s[p] * D + d_lo) * esz + v * 16);
+        }
+    }
+    __syncthreads();
+    // ---- W1 gradient of the owned elements
+    float gw[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const float w0 = W2s[h_own], w1 = W2s[H + h_own], w2 = W2s[2 * H + h_own], w3 = W2s[3 * H + h_own];
+        const unsigned hb = 1u << (h_own & 31);
+        const int hw = h_own >> 5;
+        for (int p = 0; p < P; ++p) {
+            if (!(mask[2 * p + hw] & hb)) continue;        // wave-uniform per 16-thread group, cheap either way
+            const float4 z = *reinterpret_cast<const float4*>(dz + p * 4);
+            const float dh = fmaf(z.w, w3, fmaf(z.z, w2, fmaf(z.y, w1, z.x * w0)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < NJ) {
+                    const int cc = c_own + 16 * j;
+                    float xv;
+                    if (a.xdt == MOC_F32) xv = reinterpret_cast<const float*>(region)[(size_t)p * DS + cc];
+                    else if (a.xdt == MOC_F16) xv = moc_f16_to_f32(reinterpret_cast<const uint16_t*>(region)[(size_t)p * DS + cc]);
+                    else xv = moc_bf16_to_f32(reinterpret_cast<const uint16_t*>(region)[(size_t)p * DS + cc]);
+                    gw[j] = fmaf(dh, xv, gw[j]);
+                }
+            }
+        }
+    }
+    // ---- small gradients: 16 + 4 (+ 4) sums over the pairs, one per wave, pairs strided over the lanes
+    {
+        float part = 0.f;
+        if (wave < 16) {
+            // wave w: first W2[i][4 wg + jj] with (i, jj) = (w >> 2, w & 3)
+            const int i = wave >> 2, jj = wave & 3;
+            for (int p = lane; p < P; p += 64) part = fmaf(dz[p * 4 + i], h1o[p * 4 + jj], part);
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (lane == 0) red[wave] = part;
+        }
+        __syncthreads();
+        part = 0.f;
+        if (wave < 4) {                                    // b1[4 wg + wave] = sum_p dh[p][h]
+            const int hq = wg * 4 + wave;
+            for (int p = lane; p < P; p += 64) {
+                const float4 z = *reinterpret_cast<const float4*>(dz + p * 4);
+                const float dh = fmaf(z.w, W2s[3 * H + hq], fmaf(z.z, W2s[2 * H + hq], fmaf(z.y, W2s[H + hq], z.x * W2s[hq])));
+                part += h1o[p * 4 + wave] > 0.f ? dh : 0.f;
+            }
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (lane == 0) red[16 + wave] = part;
+        } else if (wave < 8) {                             // b2[i] = sum_p dz[p][i]
+            const int i = wave - 4;
+            for (int p = lane; p < P; p += 64) part += dz[p * 4 + i];
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (lane == 0) red[20 + i] = part;
+        }
+        __syncthreads();
+    }
+    // ---- outputs
+    const float gs = a.adam.grad_scale;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < NJ) {
+            const int d = d_lo + c_own + 16 * j, e = h_own * D + d;
+            if (!a.apply_adam) { g.g_W1[e] = gw[j]; continue; }
+            adam_update(pw[j], pm[j], pv[j], gw[j] * gs, a.adam);
+            g.W1[e] = pw[j]; g.m_W1[e] = pm[j]; g.v_W1[e] = pv[j];
+            w1_image_store(g.img_dt, g.W1img, D, h_own, d, pw[j]);
+        }
+    }
+    if (small >= 0) {
+        const float gv = t < 16 ? red[(t >> 2) * 4 + (t & 3)] : t < 20 ? red[16 + (t - 16)] : red[20 + (t - 20)];
+        if (!a.apply_adam) {
+            if (small >= 5 * H) a.g_b2[small - 5 * H] = gv;
+            else if (small >= H) a.g_W2[small - H] = gv;
+            else a.g_b1[small] = gv;
+        } else {
+            adam_update(pS, pSm, pSv, gv * gs, a.adam);
+            if (small >= 5 * H) { const int i = small - 5 * H; a.b2[i] = pS; a.m_b2[i] = pSm; a.v_b2[i] = pSv; }
+            else if (small >= H) { const int i = small - H; g.W2out[i] = pS; a.m_W2[i] = pSm; a.v_W2[i] = pSv; }
+            else { a.b1[small] = pS; a.m_b1[small] = pSm; a.v_b1[small] = pSv; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ W1 gradient (+ Adam)
 struct W1Args {
     const unsigned char* X;
@@ -1222,6 +1414,32 @@ bool fused_step_ok(const moc_batch_t* B, const moc_meta_ws_t* ws) {
     return fused_step_smem(B, cap) <= FS_MAX_DYN_LDS;
 }
 
+// the wide one-launch step (pool_w1_step_wide_kernel): C <= 64, K <= 16, S <= 8192, every pair's D/16-column
+// piece in LDS
+int wide_cap(const moc_batch_t* B) {
+    int cap = 1024;
+    while (cap > 64 && (size_t)B->C * cap * 8 > 64 * 1024) cap >>= 1;
+    return cap;
+}
+size_t wide_region(const moc_batch_t* B) {
+    const size_t lists = (size_t)B->C * wide_cap(B) * 8;
+    const size_t rows = (size_t)B->C * B->topk * (B->D / 16) * moc_elem_size(B->dtype);
+    return ((lists > rows ? lists : rows) + 15) & ~(size_t)15;
+}
+size_t wide_smem(const moc_batch_t* B) {
+    const size_t C = B->C, PK = C * B->topk;
+    return wide_region(B) + C * 16 * 8 + C * 4 * 3 + PK * 4 + PK * 16 * 2 + PK * 8 + PK * 4 + (4 * H + 32) * 4 + 8 + PK * 8;
+}
+bool fused_wide_ok(const moc_batch_t* B, const moc_meta_ws_t* ws) {
+    if (!ws->W2_alt || B->topk > 16 || B->C > 64 || s_bound(B) > 8192) return false;
+    if (B->D % 512 != 0 || B->D > 1024) return false;        // D/16 = 32 or 64 columns per workgroup
+    return wide_smem(B) <= (size_t)FS_MAX_DYN_LDS;
+}
+// 0: three launches, 1: pool_w1_step_kernel, 2: pool_w1_step_wide_kernel
+int fused_step_mode(const moc_batch_t* B, const moc_meta_ws_t* ws) {
+    return fused_step_ok(B, ws) ? 1 : fused_wide_ok(B, ws) ? 2 : 0;
+}
+
 int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels,
                       int slide, uint32_t use_bits, const AdamCoef& k, float* W2out, hipStream_t s,
                       int apply_adam = 1, const P2pArgs* x = nullptr) {
@@ -1244,6 +1462,19 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
     }
     g.W1 = M->W1; g.m_W1 = M->m_W1; g.v_W1 = M->v_W1; g.W1img = (unsigned char*)M->W1_image;
     g.W2out = W2out; g.img_dt = B->dtype;
+    if (!fused_step_ok(B, ws)) {                           // wide shapes (no in-kernel exchange there)
+        MOC_REQUIRE(!x || x->world <= 1, "moc_fused_step: the in-kernel exchange needs C <= 16 and C*K*D <= %d", FS_MAX_XS);
+        static bool wide_attr = false;
+        if (!wide_attr) {
+            if (hipFuncSetAttribute((const void*)pool_w1_step_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS) != hipSuccess)
+                MOC_FAIL(MOC_ELAUNCH, "moc_fused_step: cannot raise the dynamic LDS limit to %d bytes", FS_MAX_DYN_LDS);
+            wide_attr = true;
+        }
+        pool_w1_step_wide_kernel<<<H / 4, 1024, wide_smem(B), s>>>(g, ws->pooled, ws->topk_idx, ws->topk_cnt, wide_cap(B),
+                                                                    (int)wide_region(B));
+        MOC_CHECK_LAUNCH("moc_fused_step(wide)");
+        return MOC_OK;
+    }
     const int cap = B->C <= 8 ? PS_CAP_MAX : PS_CAP_MAX / 2;
     const size_t smem = fused_step_smem(B, cap);
     static bool attr_set = false;
@@ -1336,7 +1567,7 @@ extern "C" int moc_train_grad(const moc_batch_t* B, const moc_meta_t* M, const m
     // loss + pair gradients, W1 gradient -- everything one meta-step does short of the update
     if (int rc = launch_w1_image(B, M, s)) return rc;
     if (int rc = launch_forward(B, M, ws, slide, 1, use_bits, s)) return rc;
-    if (fused_step_ok(B, ws)) return launch_fused_step(B, M, ws, labels, slide, use_bits, k, nullptr, s, 0);
+    if (fused_step_mode(B, ws)) return launch_fused_step(B, M, ws, labels, slide, use_bits, k, nullptr, s, 0);
     if (int rc = launch_pool_finish(B, M, ws, labels, slide, 1, 1, 0, use_bits, k, s)) return rc;
     return launch_w1(B, M, ws, 0, k, s, fused_ok(B, 1));
 }
@@ -1367,7 +1598,7 @@ extern "C" int moc_train_steps_dp(const moc_batch_t* B, const moc_meta_t* M, con
                 "moc_train_steps_dp: the gradient tensors must live in grad_flat[%lld]", (long long)grad_count);
     hipStream_t s = (hipStream_t)stream;
     if (int rc = launch_w1_image(B, M, s)) return rc;      // afterwards the Adam kernel keeps it in sync
-    const bool fused = fused_step_ok(B, ws);
+    const bool fused = fused_step_mode(B, ws) != 0;
     const int img_dt = B->dtype;
     AdamCoef kg = {};
     kg.grad_scale = 1.f;
@@ -1442,7 +1673,7 @@ extern "C" int moc_train_steps(const moc_batch_t* B, const moc_meta_t* M, const 
     MOC_REQUIRE(labels && slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_train_steps: bad labels/slide range");
     hipStream_t s = (hipStream_t)stream;
     if (int rc = launch_w1_image(B, M, s)) return rc;      // afterwards the W1 update keeps it in sync
-    if (fused_step_ok(B, ws)) {
+    if (fused_step_mode(B, ws)) {
         // two launches per meta-step: forward, then pooling + loss + backward + the whole Adam step.
         // W2 is read by every workgroup of the second kernel while workgroup 0 steps it: ping-pong.
         moc_meta_t Mt = *M;

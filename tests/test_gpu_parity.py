@@ -326,6 +326,36 @@ def test_train_steps_match_reference_fixtures(dev):
         assert all(int(float(opt.state[p]["step"])) == ns for p in model.parameters())
 
 
+@pytest.mark.parametrize("C,K,D,dtype", [(30, 10, 512, torch.bfloat16), (64, 10, 1024, torch.float16), (2, 10, 512, torch.float32)])
+def test_gradient_only_step_matches_autograd(dev, C, K, D, dtype):
+    """moc_train_grad (the data-parallel step's first half: gradients out, no update) on the narrow and the
+    wide one-launch kernels against autograd on the oracle."""
+    M, E = _mm(), _engine()
+    j, sizes = 40, [700, 900, 800]
+    W, We = synth.make_bank(600 + C, D, C)
+    bags, labels = synth.make_slide_set(6600 + C, sizes, D, We, C)
+    bags = [b.to(dtype) for b in bags]
+    torch.manual_seed(9)
+    ref = O.Senet(D, 4)
+    torch.manual_seed(9)
+    model = M.senet(D, 4).to(dev)
+    M.set_classifier_bank(W.to(dev), We.to(dev))
+    X, sz = M._pack(bags, dev, dtype)
+    batch = E.SlideBatch(X, sz, C, C + 4, j, K, [])
+    batch.phase_a(E.Bank.get(M.zeroshot_weights, M.zeroshot_weights_ext, dtype, dev))
+    lab = torch.tensor(labels, dtype=torch.int64, device=dev)
+    meta = E.MetaState(model, None, need_grads=True)
+    for s_i in range(len(sizes)):
+        E.train_grad(batch, meta, lab, s_i, 15)
+        got = torch.cat([t.reshape(-1) for t in meta.grads]).cpu().numpy()
+        sr = O.slide_process(bags[s_i].to(torch.float32), W, We, C, j, mask=None)
+        pooled = O.pool_top(O.mix_train(ref(sr["selected_feat"]), sr), [K])[1][K]
+        loss = torch.nn.functional.cross_entropy(pooled, torch.tensor([labels[s_i]]))
+        grads = torch.autograd.grad(loss, list(ref.parameters()))
+        exp = torch.cat([t.reshape(-1) for t in grads]).numpy()
+        np.testing.assert_allclose(got, exp, atol=2e-6, rtol=1e-4)
+
+
 def test_train_function_matches_oracle_epoch(dev):
     """moc_amd.main_moc.train over a loader == the oracle's sequential loop, same init, same masks
     (drawn from the same CPU generator state)."""
@@ -492,6 +522,9 @@ def test_full_size_properties(dev):
     (3, 10, 100, 1024, torch.float16, [700, 900, 800]),          # fp16, 2-KiB rows
     (12, 10, 60, 512, torch.float16, [900, 1000, 800, 950] * 3), # fp16, C*K = 120 pairs: general step kernels, 2-tile bank
     (30, 10, 50, 512, torch.bfloat16, [700] * 30),               # EBRAINS-30 shape: 3-tile bank, 300 pairs
+    (64, 10, 30, 1024, torch.float16, [900] * 64),               # the 64-way x 1024-d shape: wide step kernel, 640 pairs
+    (40, 16, 40, 512, torch.float32, [800] * 40),                # fp32 storage, 640 pairs of 16 per class
+    (20, 7, 400, 512, torch.bfloat16, [9000, 8000] * 10),        # S ~ 6-8 k selected rows (8 scores per thread)
 ])
 def test_train_and_eval_match_oracle_on_odd_shapes(dev, C, K, j, D, dtype, sizes):
     M = _mm()
