@@ -464,6 +464,32 @@ struct PoolLds {
     int *ncand, *topk_s;                 // [C] candidate counts, [C][K] pooled rows in value order
 };
 
+// cross entropy of the pooled logits, argmax and (train) d loss / d pooled: wave 0, one class per lane;
+// CE_OFF = widest xor offset (8: C <= 16, 32: C <= 64)
+template <int CE_OFF>
+__device__ __forceinline__ void ce_wave0(const FinishArgs& a, int b, int C, int y, const float* pooled_s, float* dpool,
+                                         bool write_out) {
+    const int lane = threadIdx.x & 63;
+    if ((threadIdx.x >> 6) != 0) return;
+    const float xv = lane < C ? pooled_s[lane] : -INFINITY;
+    float mx = xv;
+    int arg = lane < C ? lane : 0x7fffffff;
+    for (int off = CE_OFF; off > 0; off >>= 1) {
+        const float om = __shfl_xor(mx, off, 64);
+        const int oa = __shfl_xor(arg, off, 64);
+        if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
+    }
+    const float ex = lane < C ? expf(xv - mx) : 0.f;
+    float se = ex;
+    for (int off = CE_OFF; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
+    const float lse = mx + logf(se);
+    if (lane < C && a.train) dpool[lane] = expf(xv - lse) - (lane == y ? 1.f : 0.f);
+    if (lane == 0 && write_out) {
+        a.loss[b] = lse - pooled_s[y];
+        a.pred[b] = arg;
+    }
+}
+
 // Pooling + loss of slide b by ONE workgroup of 16 waves (all threads must call): leaves the pooled
 // rows in L.topk_s, the pooled logits in L.pooled_s and (train) d loss/d pooled in L.dpool; returns
 // k = rows pooled per class.  `write_out`: this workgroup also publishes pooled/topk/loss/pred.
@@ -613,26 +639,8 @@ __device__ __forceinline__ int pool_phase(const FinishArgs& a, int b, const Pool
     }
     __syncthreads();
     MOC_STAMP(13);
-    // ---- cross entropy, argmax: wave 0, one class per lane (C <= 16)
-    if (wave == 0) {
-        const float xv = lane < C ? pooled_s[lane] : -INFINITY;
-        float mx = xv;
-        int arg = lane < C ? lane : 0x7fffffff;
-        for (int off = CE_OFF; off > 0; off >>= 1) {   // lanes 0..2*CE_OFF-1 hold the classes
-            const float om = __shfl_xor(mx, off, 64);
-            const int oa = __shfl_xor(arg, off, 64);
-            if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
-        }
-        const float ex = lane < C ? expf(xv - mx) : 0.f;
-        float se = ex;
-        for (int off = CE_OFF; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
-        const float lse = mx + logf(se);
-        if (lane < C && a.train) dpool[lane] = expf(xv - lse) - (lane == y ? 1.f : 0.f);
-        if (lane == 0 && write_out) {
-            a.loss[b] = lse - pooled_s[y];
-            a.pred[b] = arg;
-        }
-    }
+    // ---- cross entropy, argmax: wave 0, one class per lane
+    ce_wave0<CE_OFF>(a, b, C, y, pooled_s, dpool, write_out);
     *base_out = base;
     return k;
 }
@@ -978,18 +986,12 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
 // its hidden row: dh[p][h] = mask_p[h] ? sum_i dz[p][i] W2[i][h] : 0 is re-formed on the fly.  The small
 // tensors are split by hidden unit: workgroup g also owns W2[:, 4g..4g+3] and b1[4g..4g+3] (16 wave-wide
 // reductions over the pairs), workgroup 0 b2.
-struct WideLds {
-    unsigned char* region;      // candidate lists during pooling, then the pairs' row pieces
-    float *dz, *h1o;            // [P][4] gate derivatives, [P][4] H1 of this workgroup's four hidden units
-    unsigned* mask;             // [P][2] ReLU mask of the pair's hidden row
-    int* sidx;                  // [P]
-    int64_t* prow;              // [P]
-    float* W2s;                 // [4][H]
-    float* red;                 // [16 + 4 + 4] reduced small gradients
-};
+constexpr int WD_PCH = 128;      // pairs per chunk of the W1 gradient
+
 
 __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, float* pooled_out, int32_t* topk_idx_out,
-                                                                 int32_t* topk_cnt_out, int PS_CAP, int region_bytes) {
+                                                                 int32_t* topk_cnt_out, int PS_CAP, int region_bytes,
+                                                                 int external_pool) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FinishArgs& a = g.f;
     const int b = a.slide0, C = a.C, K = a.K, D = a.D;
@@ -1014,15 +1016,19 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     int64_t* prow_s = reinterpret_cast<int64_t*>((reinterpret_cast<uintptr_t>(red + 32) + 7) & ~(uintptr_t)7);   // [P]
 
     // ---- operands that do not depend on this slide: requested first, consumed last.
-    // thread t owns hidden unit h = t >> 4 and columns d_lo + (t & 15) + 16 j, j < DS / 16 (DS = 32 or 64)
-    const int h_own = t >> 4, c_own = t & 15, NJ = DS / 16;
+    // The W1 gradient of this workgroup is a [64 x DS] tile product on the fp32 matrix cores: wave w < 4*DS/16
+    // owns the 16 x 16 tile (hidden units 16 (w / NTN) .., columns d_lo + 16 (w % NTN) ..); lane l ends with
+    // elements (h0 + (l >> 4) * 4 + i, d0 + (l & 15)), i < 4.
+    const int NTN = DS / 16;                              // n-tiles (2 or 4)
+    const bool has_tile = wave < 4 * NTN;
+    const int h0 = (wave / NTN) * 16, d0 = d_lo + (wave % NTN) * 16;
     float pw[4], pm[4], pv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        pw[j] = pm[j] = pv[j] = 0.f;
-        if (j < NJ && a.apply_adam) {
-            const int e = h_own * D + d_lo + c_own + 16 * j;
-            pw[j] = g.W1[e]; pm[j] = g.m_W1[e]; pv[j] = g.v_W1[e];
+    for (int i = 0; i < 4; ++i) {
+        pw[i] = pm[i] = pv[i] = 0.f;
+        if (has_tile && a.apply_adam) {
+            const int e = (h0 + (lane >> 4) * 4 + i) * D + d0 + (lane & 15);
+            pw[i] = g.W1[e]; pm[i] = g.m_W1[e]; pv[i] = g.v_W1[e];
         }
     }
     if (t < 4 * H) W2s[t] = a.W2[t];
@@ -1038,8 +1044,21 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
         else { pS = a.b1[small]; pSm = a.m_b1[small]; pSv = a.v_b1[small]; }
     }
     int64_t base;
-    const PoolLds L = {list, wmax, pooled_s, dpool, ncand, topk_s};
-    const int k = pool_phase<8, 32, 2>(a, b, L, PS_CAP, wg == 0, pooled_out, topk_idx_out, topk_cnt_out, &base);
+    int k;
+    if (external_pool) {
+        // more than 8192 selected rows possible: the top-K came from topk_mean_kernel (one workgroup per class,
+        // radix select); pick it up, add loss / argmax / d loss
+        base = a.base_host >= 0 ? a.base_host : a.row_off[b];
+        const int y = (int)a.labels[b];
+        for (int e = t; e < C * K; e += 1024) topk_s[e] = a.topk_idx[(int64_t)b * C * K + e];
+        if (t < C) pooled_s[t] = a.pooled[(int64_t)b * C + t];
+        k = a.topk_cnt[(int64_t)b * C];
+        __syncthreads();
+        ce_wave0<32>(a, b, C, y, pooled_s, dpool, wg == 0);
+    } else {
+        const PoolLds L = {list, wmax, pooled_s, dpool, ncand, topk_s};
+        k = pool_phase<8, 32, 2>(a, b, L, PS_CAP, wg == 0, pooled_out, topk_idx_out, topk_cnt_out, &base);
+    }
     __syncthreads();
     // ---- pairs
     const int P = C * k;
@@ -1067,39 +1086,51 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
         if (bits) atomicOr(&mask[2 * p + (v >> 3)], bits << ((v & 7) * 4));
         if (v == wg) *reinterpret_cast<float4*>(h1o + p * 4) = hv;
     }
-    // this workgroup's piece of every pair's bag row, as stored (DS * esz bytes, 16-B pieces)
+    __syncthreads();                                       // masks complete
+    // ---- W1 gradient: dW1[h][d] = sum_p dh[p][h] x[p][d], pairs in chunks of WD_PCH through `region`:
+    // [PCH][DS] pieces of the pairs' rows as stored + [PCH][64] fp32 dh, then v_mfma_f32_16x16x4_f32 over p
+    f32x4_t gacc = {0.f, 0.f, 0.f, 0.f};
     {
-        const int ppr = DS * esz / 16;                     // pieces per pair
-        for (int e = t; e < P * ppr; e += 1024) {
-            const int p = e / ppr, v = e - p * ppr;
-            *reinterpret_cast<uint4*>(region + ((size_t)p * ppr + v) * 16) =
-                *reinterpret_cast<const uint4*>(a.X + (prow_s[p] * D + d_lo) * esz + v * 16);
-        }
-    }
-    __syncthreads();
-    // ---- W1 gradient of the owned elements
-    float gw[4] = {0.f, 0.f, 0.f, 0.f};
-    {
-        const float w0 = W2s[h_own], w1 = W2s[H + h_own], w2 = W2s[2 * H + h_own], w3 = W2s[3 * H + h_own];
-        const unsigned hb = 1u << (h_own & 31);
-        const int hw = h_own >> 5;
-        for (int p = 0; p < P; ++p) {
-            if (!(mask[2 * p + hw] & hb)) continue;        // wave-uniform per 16-thread group, cheap either way
-            const float4 z = *reinterpret_cast<const float4*>(dz + p * 4);
-            const float dh = fmaf(z.w, w3, fmaf(z.z, w2, fmaf(z.y, w1, z.x * w0)));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j < NJ) {
-                    const int cc = c_own + 16 * j;
-                    float xv;
-                    if (a.xdt == MOC_F32) xv = reinterpret_cast<const float*>(region)[(size_t)p * DS + cc];
-                    else if (a.xdt == MOC_F16) xv = moc_f16_to_f32(reinterpret_cast<const uint16_t*>(region)[(size_t)p * DS + cc]);
-                    else xv = moc_bf16_to_f32(reinterpret_cast<const uint16_t*>(region)[(size_t)p * DS + cc]);
-                    gw[j] = fmaf(dh, xv, gw[j]);
+        const int ppr = DS * esz / 16;                     // 16-B pieces per pair
+        unsigned char* xraw = region;                                              // [PCH][DS * esz]
+        float* dh_s = reinterpret_cast<float*>(region + (size_t)WD_PCH * DS * esz); // [PCH][64]
+        for (int c0 = 0; c0 < P; c0 += WD_PCH) {
+            const int n = P - c0 < WD_PCH ? P - c0 : WD_PCH;
+            const int n4 = (n + 3) & ~3;
+            if (c0 > 0) __syncthreads();                   // previous chunk consumed
+            for (int e = t; e < n * ppr; e += 1024) {
+                const int pp = e / ppr, v = e - pp * ppr;
+                *reinterpret_cast<uint4*>(xraw + ((size_t)pp * ppr + v) * 16) =
+                    *reinterpret_cast<const uint4*>(a.X + (prow_s[c0 + pp] * D + d_lo) * esz + v * 16);
+            }
+            for (int e = t; e < n4 * 64; e += 1024) {
+                const int pp = e >> 6, h = e & 63;
+                float v = 0.f;
+                if (pp < n && (mask[2 * (c0 + pp) + (h >> 5)] >> (h & 31) & 1u)) {
+                    const float4 z = *reinterpret_cast<const float4*>(dz + (c0 + pp) * 4);
+                    v = fmaf(z.w, W2s[3 * H + h], fmaf(z.z, W2s[2 * H + h], fmaf(z.y, W2s[H + h], z.x * W2s[h])));
+                }
+                dh_s[pp * 64 + h] = v;
+            }
+            __syncthreads();
+            if (has_tile) {
+                const int kq = lane >> 4, li = lane & 15;
+                for (int ks = 0; ks < n4; ks += 4) {
+                    const int pp = ks + kq;
+                    const float av = dh_s[pp * 64 + h0 + li];
+                    float bv = 0.f;
+                    if (pp < n) {
+                        const int cc = (d0 - d_lo) + li;
+                        if (a.xdt == MOC_F32) bv = reinterpret_cast<const float*>(xraw)[(size_t)pp * DS + cc];
+                        else if (a.xdt == MOC_F16) bv = moc_f16_to_f32(reinterpret_cast<const uint16_t*>(xraw)[(size_t)pp * DS + cc]);
+                        else bv = moc_bf16_to_f32(reinterpret_cast<const uint16_t*>(xraw)[(size_t)pp * DS + cc]);
+                    }
+                    gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, gacc, 0, 0, 0);
                 }
             }
         }
     }
+    __syncthreads();
     // ---- small gradients: 16 + 4 (+ 4) sums over the pairs, one per wave, pairs strided over the lanes
     {
         float part = 0.f;
@@ -1131,14 +1162,14 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     }
     // ---- outputs
     const float gs = a.adam.grad_scale;
+    if (has_tile) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (j < NJ) {
-            const int d = d_lo + c_own + 16 * j, e = h_own * D + d;
-            if (!a.apply_adam) { g.g_W1[e] = gw[j]; continue; }
-            adam_update(pw[j], pm[j], pv[j], gw[j] * gs, a.adam);
-            g.W1[e] = pw[j]; g.m_W1[e] = pm[j]; g.v_W1[e] = pv[j];
-            w1_image_store(g.img_dt, g.W1img, D, h_own, d, pw[j]);
+        for (int i = 0; i < 4; ++i) {
+            const int h = h0 + (lane >> 4) * 4 + i, d = d0 + (lane & 15), e = h * D + d;
+            if (!a.apply_adam) { g.g_W1[e] = gacc[i]; continue; }
+            adam_update(pw[i], pm[i], pv[i], gacc[i] * gs, a.adam);
+            g.W1[e] = pw[i]; g.m_W1[e] = pm[i]; g.v_W1[e] = pv[i];
+            w1_image_store(g.img_dt, g.W1img, D, h, d, pw[i]);
         }
     }
     if (small >= 0) {
@@ -1423,7 +1454,7 @@ int wide_cap(const moc_batch_t* B) {
 }
 size_t wide_region(const moc_batch_t* B) {
     const size_t lists = (size_t)B->C * wide_cap(B) * 8;
-    const size_t rows = (size_t)B->C * B->topk * (B->D / 16) * moc_elem_size(B->dtype);
+    const size_t rows = (size_t)WD_PCH * ((B->D / 16) * moc_elem_size(B->dtype) + 64 * sizeof(float));   // row pieces + dh of one chunk
     return ((lists > rows ? lists : rows) + 15) & ~(size_t)15;
 }
 size_t wide_smem(const moc_batch_t* B) {
@@ -1431,7 +1462,7 @@ size_t wide_smem(const moc_batch_t* B) {
     return wide_region(B) + C * 16 * 8 + C * 4 * 3 + PK * 4 + PK * 16 * 2 + PK * 8 + PK * 4 + (4 * H + 32) * 4 + 8 + PK * 8;
 }
 bool fused_wide_ok(const moc_batch_t* B, const moc_meta_ws_t* ws) {
-    if (!ws->W2_alt || B->topk > 16 || B->C > 64 || s_bound(B) > 8192) return false;
+    if (!ws->W2_alt || B->topk > 16 || B->C > 64) return false;      // (S > 8192: pooling by topk_mean_kernel first)
     if (B->D % 512 != 0 || B->D > 1024) return false;        // D/16 = 32 or 64 columns per workgroup
     return wide_smem(B) <= (size_t)FS_MAX_DYN_LDS;
 }
@@ -1470,8 +1501,13 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
                 MOC_FAIL(MOC_ELAUNCH, "moc_fused_step: cannot raise the dynamic LDS limit to %d bytes", FS_MAX_DYN_LDS);
             wide_attr = true;
         }
+        const int external = s_bound(B) > 8192;
+        if (external) {
+            if (int rc = launch_pool(B, ws, slide, 1, s)) return rc;
+            a.topk_idx = ws->topk_idx; a.topk_cnt = ws->topk_cnt;
+        }
         pool_w1_step_wide_kernel<<<H / 4, 1024, wide_smem(B), s>>>(g, ws->pooled, ws->topk_idx, ws->topk_cnt, wide_cap(B),
-                                                                    (int)wide_region(B));
+                                                                    (int)wide_region(B), external);
         MOC_CHECK_LAUNCH("moc_fused_step(wide)");
         return MOC_OK;
     }
