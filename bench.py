@@ -179,7 +179,17 @@ def main():
         avg_ms = sum(ms) / len(ms)
         avg_bytes = sum(by) / len(by)
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "scores_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        # the kernel moc_scores launches for this shape (moc_scores.hip), as rocprofv3 names it
+        esz = 4 if a.dtype == "fp32" else 2
+        nt = (C + 4 + 15) // 16
+        half, f16 = ("true", "true" if a.dtype == "fp16" else "false") if esz == 2 else ("false", "false")
+        if nt <= (3 if esz == 2 else 4):
+            kname = f"scores_stream_kernel<{16 if (D * esz) % 1024 == 0 else 8}, {half}, {nt}, {f16}>"
+        elif esz == 2 and nt <= 8 and D % 64 == 0:
+            kname = f"scores_wide_kernel<{nt}, {f16}>"
+        else:
+            kname = f"scores_kernel<{512 if D % 512 == 0 else 256}, {half}, {f16}>"
+        roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
                 "launches": len(ms)}
