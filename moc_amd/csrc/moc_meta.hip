@@ -1162,28 +1162,44 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     }
     // ---- outputs
     const float gs = a.adam.grad_scale;
+    float gv = 0.f;
+    if (small >= 0) gv = t < 16 ? red[(t >> 2) * 4 + (t & 3)] : t < 20 ? red[16 + (t - 16)] : red[20 + (t - 20)];
+    if (!a.apply_adam) {                                   // gradients out (data-parallel step with a collective)
+        if (has_tile)
+            for (int i = 0; i < 4; ++i) g.g_W1[(h0 + (lane >> 4) * 4 + i) * D + d0 + (lane & 15)] = gacc[i];
+        if (small >= 5 * H) a.g_b2[small - 5 * H] = gv;
+        else if (small >= H) a.g_W2[small - H] = gv;
+        else if (small >= 0) a.g_b1[small] = gv;
+        return;
+    }
+    if (g.x.world > 1) {                                   // one-shot exchange over xGMI (moc_p2p.h), as in the narrow kernel
+        __shared__ int p2p_ok;
+        const int64_t nW1 = (int64_t)H * D;
+        if (has_tile)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p2p_push(g.x, (int64_t)(h0 + (lane >> 4) * 4 + i) * D + d0 + (lane & 15), gacc[i]);
+        if (small >= 0) p2p_push(g.x, nW1 + small, gv);
+        if (!p2p_signal_wait(g.x, wg, &p2p_ok)) return;   // time-out: reported through g.x.error, no update
+        if (has_tile)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                gacc[i] = p2p_sum(g.x, (int64_t)(h0 + (lane >> 4) * 4 + i) * D + d0 + (lane & 15), gacc[i]);
+        if (small >= 0) gv = p2p_sum(g.x, nW1 + small, gv);
+    }
     if (has_tile) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int h = h0 + (lane >> 4) * 4 + i, d = d0 + (lane & 15), e = h * D + d;
-            if (!a.apply_adam) { g.g_W1[e] = gacc[i]; continue; }
             adam_update(pw[i], pm[i], pv[i], gacc[i] * gs, a.adam);
             g.W1[e] = pw[i]; g.m_W1[e] = pm[i]; g.v_W1[e] = pv[i];
             w1_image_store(g.img_dt, g.W1img, D, h, d, pw[i]);
         }
     }
     if (small >= 0) {
-        const float gv = t < 16 ? red[(t >> 2) * 4 + (t & 3)] : t < 20 ? red[16 + (t - 16)] : red[20 + (t - 20)];
-        if (!a.apply_adam) {
-            if (small >= 5 * H) a.g_b2[small - 5 * H] = gv;
-            else if (small >= H) a.g_W2[small - H] = gv;
-            else a.g_b1[small] = gv;
-        } else {
-            adam_update(pS, pSm, pSv, gv * gs, a.adam);
-            if (small >= 5 * H) { const int i = small - 5 * H; a.b2[i] = pS; a.m_b2[i] = pSm; a.v_b2[i] = pSv; }
-            else if (small >= H) { const int i = small - H; g.W2out[i] = pS; a.m_W2[i] = pSm; a.v_W2[i] = pSv; }
-            else { a.b1[small] = pS; a.m_b1[small] = pSm; a.v_b1[small] = pSv; }
-        }
+        adam_update(pS, pSm, pSv, gv * gs, a.adam);
+        if (small >= 5 * H) { const int i = small - 5 * H; a.b2[i] = pS; a.m_b2[i] = pSm; a.v_b2[i] = pSv; }
+        else if (small >= H) { const int i = small - H; g.W2out[i] = pS; a.m_W2[i] = pSm; a.v_W2[i] = pSv; }
+        else { a.b1[small] = pS; a.m_b1[small] = pSm; a.v_b1[small] = pSv; }
     }
 }
 
@@ -1493,8 +1509,7 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
     }
     g.W1 = M->W1; g.m_W1 = M->m_W1; g.v_W1 = M->v_W1; g.W1img = (unsigned char*)M->W1_image;
     g.W2out = W2out; g.img_dt = B->dtype;
-    if (!fused_step_ok(B, ws)) {                           // wide shapes (no in-kernel exchange there)
-        MOC_REQUIRE(!x || x->world <= 1, "moc_fused_step: the in-kernel exchange needs C <= 16 and C*K*D <= %d", FS_MAX_XS);
+    if (!fused_step_ok(B, ws)) {                           // wide shapes
         static bool wide_attr = false;
         if (!wide_attr) {
             if (hipFuncSetAttribute((const void*)pool_w1_step_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS) != hipSuccess)
@@ -1665,7 +1680,7 @@ extern "C" int moc_p2p_step_supported(int C, int topk, int D, int topj) {
     moc_meta_ws_t ws = {};
     float dummy;
     ws.W2_alt = &dummy;
-    return C >= 1 && topk >= 1 && D >= 1 && topj >= 1 && fused_step_ok(&B, &ws) ? 1 : 0;
+    return C >= 1 && topk >= 1 && D >= 1 && topj >= 1 && fused_step_mode(&B, &ws) != 0 ? 1 : 0;
 }
 
 extern "C" int moc_train_steps_p2p(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
@@ -1675,8 +1690,8 @@ extern "C" int moc_train_steps_p2p(const moc_batch_t* B, const moc_meta_t* M, co
     if (int rc = check_meta(B, M, ws, "moc_train_steps_p2p", true, false)) return rc;
     MOC_REQUIRE(labels && slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_train_steps_p2p: bad labels/slide range");
     MOC_REQUIRE(comm, "moc_train_steps_p2p: null communicator");
-    MOC_REQUIRE(fused_step_ok(B, ws), "moc_train_steps_p2p: shape outside the one-launch step (C<=16, K<=16, C*K*D<=%d); "
-                "use moc_train_steps_dp", FS_MAX_XS);
+    MOC_REQUIRE(fused_step_mode(B, ws) != 0, "moc_train_steps_p2p: shape outside the one-launch steps (K <= 16, C <= 64, "
+                "D in {512, 1024} beyond C = 16); use moc_train_steps_dp");
     hipStream_t s = (hipStream_t)stream;
     if (int rc = launch_w1_image(B, M, s)) return rc;
     moc_meta_t Mt = *M;

@@ -27,7 +27,7 @@ def _steps(world):
     return len(SIZES) // world
 
 
-def _worker(rank, world, port, q, exchange):
+def _worker(rank, world, port, q, exchange, C):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                           MOC_DP_EXCHANGE=exchange, MOC_P2P_TIMEOUT_MS="20000")
@@ -37,7 +37,7 @@ def _worker(rank, world, port, q, exchange):
         torch.set_num_threads(2)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dev = torch.device("cuda:0")
-        C, j, K = 2, 100, 10
+        j, K = 100, 10
         W, We = synth.make_bank(77, 512, C)
         sizes = SIZES
         bags, labels = synth.make_slide_set(7700, sizes, 512, We, C)
@@ -53,8 +53,10 @@ def _worker(rank, world, port, q, exchange):
         torch.cuda.synchronize()
         assert mdist.exchange_error() == 0
         losses = mdist.train_dp.last[0].meta_ws()[0]["loss"].cpu().numpy()
-        ev = mdist.evaluation_dp(model, res, dev, H.make_args(C, j, K), labels, mine,
-                                 [[r + world * t for t in range(T)] for r in range(world)])
+        ev = None
+        if C <= len(SIZES):          # the AUC needs every class among the slides (sklearn's rule, the reference's too)
+            ev = mdist.evaluation_dp(model, res, dev, H.make_args(C, j, K), labels, mine,
+                                     [[r + world * t for t in range(T)] for r in range(world)])
         q.put((rank, (H.flat_params(model), losses, ev, int(float(opt.state[next(model.parameters())]["step"])),
                       mdist.train_dp.exchange)))
         mdist.shutdown()
@@ -64,15 +66,15 @@ def _worker(rank, world, port, q, exchange):
         q.put((rank, "ERR " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("exchange,world", [("auto", 2), ("rccl", 2), ("auto", 4)])
-def test_train_dp_matches_minibatch_oracle(gpu_device, exchange, world):
+@pytest.mark.parametrize("exchange,world,C", [("auto", 2, 2), ("rccl", 2, 2), ("auto", 4, 2), ("auto", 2, 30), ("rccl", 2, 30)])
+def test_train_dp_matches_minibatch_oracle(gpu_device, exchange, world, C):
     import helpers as H
     from moc_amd import synth
     from oracle import moc_oracle as O
     ctx = mp.get_context("spawn")
     q, port = ctx.Queue(), _free_port()
     T = _steps(world)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, C)) for r in range(world)]
     for p in procs:
         p.start()
     out = dict(q.get(timeout=300) for _ in range(world))
@@ -87,7 +89,7 @@ def test_train_dp_matches_minibatch_oracle(gpu_device, exchange, world):
         # the path asked for is the path taken (auto = the in-kernel exchange on one node)
         assert out[r][4] == ("p2p" if exchange == "auto" else "collective")
     # oracle: T synchronous steps, each the mean gradient of one slide per rank
-    C, j, K = 2, 100, 10
+    j, K = 100, 10
     W, We = synth.make_bank(77, 512, C)
     sizes = SIZES
     bags, labels = synth.make_slide_set(7700, sizes, 512, We, C)
@@ -116,6 +118,8 @@ def test_train_dp_matches_minibatch_oracle(gpu_device, exchange, world):
         np.testing.assert_allclose(out[rank][1], [ref_losses[rank + world * t] for t in range(T)], atol=1e-4)
     H.assert_adam_params_close(out[0][0], H.flat_params(ref), H.flat_state(ropt, "exp_avg_sq"), step=T,
                                grad_noise=1e-6, what=f"dp{world}")
+    if C > len(SIZES):
+        return
     ev_ref = O.evaluation(ref, bags, labels, W, We, C, j, K)
     for rank in range(world):
         ev = out[rank][2]
