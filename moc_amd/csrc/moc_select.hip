@@ -131,6 +131,7 @@ struct CompactArgs {
     float* cand;
     const unsigned char* X;
     unsigned char* selected_feat;   // nullable
+    int cand_inline;                // compact_kernel copies the candidate columns itself
     int64_t stride;
     int C, row_bytes;
 };
@@ -152,14 +153,35 @@ __global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a) {
             const int64_t o = base + running + pos;
             a.sel_idx[o] = i;
             a.sel_row[o] = xbase + (a.kept ? a.kept[base + i] : i);
-            const float* s = a.stats + base + i;
-            float* c = a.cand + o;
-            for (int k = 0; k < 2 * C + 1; ++k) c[(int64_t)k * a.stride] = s[(int64_t)k * a.stride];
-            c[(int64_t)(2 * C + 1) * a.stride] = s[(int64_t)(2 * C + 2) * a.stride];   // s_beta = max background
+            if (a.cand_inline) {                       // few columns (C <= 4): copied here, no second launch
+                const float* s = a.stats + base + i;
+                float* c = a.cand + o;
+                for (int k = 0; k < 2 * C + 1; ++k) c[(int64_t)k * a.stride] = s[(int64_t)k * a.stride];
+                c[(int64_t)(2 * C + 1) * a.stride] = s[(int64_t)(2 * C + 2) * a.stride];   // s_beta = max background
+            }
         }
         running += tot;
     }
     if (threadIdx.x == 0) a.n_sel[b] = running;
+}
+
+// grid (ceil(max_rows / 256), ceil((2C+2) / CAND_COLS), n_slides): candidate columns of the selected rows,
+// one selected slot per thread, CAND_COLS columns per workgroup.  (With the copy inside compact_kernel -- one
+// workgroup per slide, 2C+2 strided columns per thread -- that kernel took 1.6 ms at 64 classes, longer than
+// the score pass.)
+constexpr int CAND_COLS = 8;
+__global__ __launch_bounds__(256) void cand_gather_kernel(CompactArgs a) {
+    const int b = blockIdx.z, C = a.C;
+    const int64_t base = a.row_off[b];
+    const int S = a.n_sel[b];
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= S) return;
+    const int i = a.sel_idx[base + o];
+    const int k_lo = blockIdx.y * CAND_COLS, k_hi = min(k_lo + CAND_COLS, 2 * C + 2);
+    const float* s = a.stats + base + i;
+    float* c = a.cand + base + o;
+    for (int k = k_lo; k < k_hi; ++k)                  // candidate k <- statistic k; the last one is s_beta = max background
+        c[(int64_t)k * a.stride] = s[(int64_t)(k == 2 * C + 1 ? 2 * C + 2 : k) * a.stride];
 }
 
 // grid (ceil(max_rows/16), n_slides): copies selected rows (16 B per thread per step)
@@ -305,7 +327,12 @@ extern "C" int moc_gather_candidates(const moc_batch_t* B, void* selected_feat, 
     a.cand = B->cand; a.X = (const unsigned char*)B->X; a.selected_feat = (unsigned char*)selected_feat;
     a.stride = B->total_rows; a.C = B->C; a.row_bytes = B->D * moc_elem_size(B->dtype);
     hipStream_t s = (hipStream_t)stream;
+    a.cand_inline = B->C <= 4;
     compact_kernel<<<B->n_slides, 1024, 0, s>>>(a);
+    if (!a.cand_inline) {
+        MOC_CHECK_LAUNCH("moc_gather_candidates(compact)");
+        cand_gather_kernel<<<dim3(moc_cdiv(B->max_rows, 256), moc_cdiv(2 * B->C + 2, CAND_COLS), B->n_slides), 256, 0, s>>>(a);
+    }
     MOC_CHECK_LAUNCH("moc_gather_candidates(compact)");
     if (selected_feat) {
         int gx = moc_cdiv(B->max_rows, 16);
