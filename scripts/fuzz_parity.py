@@ -1,0 +1,89 @@
+"""Randomised parity sweep (not part of the test suite): random class counts, dims, storage types, ragged
+slide sizes, topj / topk, discarded selectors -- two epochs of train() and one evaluation() against the
+oracle, the same comparison tests/test_gpu_parity.py::test_train_and_eval_match_oracle_on_odd_shapes makes.
+
+    python scripts/fuzz_parity.py [--cases 60] [--seed 1]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as H  # noqa: E402
+from moc_amd import main_moc as M, synth  # noqa: E402
+from oracle import moc_oracle as O  # noqa: E402
+
+
+def one_case(rng, dev, idx):
+    C = int(rng.choice([2, 2, 3, 4, 5, 8, 12, 16, 20, 30, 40]))
+    D = int(rng.choice([256, 512, 512, 768, 1024]))
+    dtype = [torch.float32, torch.bfloat16, torch.float16][int(rng.integers(0, 3))]
+    K = int(rng.choice([1, 3, 5, 10, 10, 16, 20]))
+    j = int(rng.choice([5, 40, 100, 400, 3000]))
+    ns = int(rng.integers(max(2, min(C, 6)), 9)) if C <= 8 else int(rng.integers(2, 5))
+    big = rng.random() < 0.25                                  # some cases with enough rows for S > 4096 / > 8192
+    sizes = [int(rng.integers(1, 40)) if rng.random() < 0.15 else
+             int(rng.integers(6000, 14000)) if big else int(rng.integers(200, 2500)) for _ in range(ns)]
+    all_sel = ["delta_softmax", "delta_diff", "bottomk"]
+    discard = [s for s in all_sel if rng.random() < 0.2]
+    desc = f"#{idx} C={C} D={D} {str(dtype).split('.')[-1]} K={K} j={j} sizes={sizes} discard={discard}"
+    W, We = synth.make_bank(int(rng.integers(1, 1 << 30)), D, C)
+    bags, labels = synth.make_slide_set(int(rng.integers(1, 1 << 30)), sizes, D, We, C)
+    labels = [int(rng.integers(0, C)) for _ in sizes]
+    bags = [b.to(dtype) for b in bags]
+    ref_bags = [b.to(torch.float32) for b in bags]
+    seed = int(rng.integers(1, 1 << 30))
+    torch.manual_seed(seed)
+    ref_model = O.Senet(D, 4)
+    ref_opt = O.make_optimizer(ref_model)
+    torch.manual_seed(seed)
+    model = M.senet(D, 4).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    M.set_classifier_bank(W.to(dev), We.to(dev))
+    args = H.make_args(C, j, K, discard)
+    res = M.ResidentBags(bags, labels, dev)
+    for epoch in range(2):
+        torch.manual_seed(seed + 1 + epoch)
+        ref_losses = O.train_epoch(ref_model, ref_opt, ref_bags, labels, W, We, C, j, K, discard=discard)
+        torch.manual_seed(seed + 1 + epoch)
+        M.train(model, res, opt, dev, args)
+        got = M.train.last[0].meta_ws()[0]["loss"].cpu().numpy()
+        np.testing.assert_allclose(got, np.asarray(ref_losses), atol=1e-4, err_msg=desc)
+    H.assert_adam_params_close(H.flat_params(model), H.flat_params(ref_model), H.flat_state(ref_opt, "exp_avg_sq"),
+                               step=2 * len(sizes), grad_noise=1e-6, what=desc)
+    if len(set(labels)) == C:                                  # AUC needs every class present
+        ev_ref = O.evaluation(ref_model, ref_bags, labels, W, We, C, j, K, discard=discard)
+        ev = M.evaluation(model, res, dev, args)
+        assert abs(ev["loss"] - ev_ref["loss"]) < 1e-4 and ev["acc"] == ev_ref["acc"] and abs(ev["auc"] - ev_ref["auc"]) < 2e-3, \
+            f"{desc}: evaluation {ev} vs {ev_ref}"
+    return desc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(a.seed)
+    bad = 0
+    t0 = time.time()
+    for i in range(a.cases):
+        try:
+            desc = one_case(rng, dev, i)
+            print("ok  ", desc, flush=True)
+        except AssertionError as e:
+            bad += 1
+            print("FAIL", str(e)[:1500], flush=True)
+    print(f"{a.cases - bad}/{a.cases} cases agree with the oracle ({time.time() - t0:.0f} s)")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
