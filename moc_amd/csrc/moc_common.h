@@ -111,6 +111,28 @@ __device__ __forceinline__ int moc_block_flag_scan(bool flag, int* wave_tot, int
     return off + before;
 }
 
+// Exclusive prefix over a block of small counts (same contract as moc_block_flag_scan).
+__device__ __forceinline__ int moc_block_count_scan(int cnt, int* wave_tot, int* block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
+    int inc = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int w = 0; w < nwave; ++w) {
+        const int t = wave_tot[w];
+        if (w < wave) off += t;
+        tot += t;
+    }
+    __syncthreads();
+    *block_total = tot;
+    return off + inc - cnt;
+}
+
 // ---- diagnostic build only (-DMOC_STAMPS, make stamps): constant-clock (100 MHz) time stamps of
 // kernel phases, written by thread 0 of workgroup (0,0) to a global array that nothing else reads.
 #ifdef MOC_STAMPS

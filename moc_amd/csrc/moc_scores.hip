@@ -76,6 +76,9 @@ __global__ void prepare_bank_f32_kernel(const float* W, const float* We, int D, 
 }
 
 // ------------------------------------------------------------------ mask -> kept
+// One workgroup per slide; a thread owns 16 consecutive rows: its 16 flag bytes are requested at once (the
+// flags may sit in pinned host memory: one PCIe round trip per 16,384 rows instead of one per 1,024), one
+// block scan of the per-thread counts places them.
 __global__ __launch_bounds__(1024) void mask_compact_kernel(const uint8_t* mask, const int64_t* row_off,
                                                             int32_t* kept, int32_t* n_kept) {
     __shared__ int wave_tot[17];
@@ -83,12 +86,23 @@ __global__ __launch_bounds__(1024) void mask_compact_kernel(const uint8_t* mask,
     const int64_t base = row_off[b];
     const int n = (int)(row_off[b + 1] - base);
     int running = 0;
-    for (int c0 = 0; c0 < n; c0 += blockDim.x) {
-        const int i = c0 + threadIdx.x;
-        const bool keep = i < n && mask[base + i] != 0;
+    for (int c0 = 0; c0 < n; c0 += 16 * 1024) {
+        const int i0 = c0 + (int)threadIdx.x * 16;
+        unsigned bits = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = i0 + q;
+            const uint8_t f = mask[base + (i < n ? i : n - 1)];
+            bits |= (i < n && f != 0 ? 1u : 0u) << q;
+        }
         int tot;
-        const int pos = moc_block_flag_scan(keep, wave_tot, &tot);
-        if (keep) kept[base + running + pos] = i;
+        int pos = moc_block_count_scan(__popc(bits), wave_tot, &tot);
+        int32_t* out = kept + base + running + pos;
+        while (bits) {                                   // ascending: lowest set bit first
+            const int q = __ffs((int)bits) - 1;
+            *out++ = i0 + q;
+            bits &= bits - 1;
+        }
         running += tot;
     }
     if (threadIdx.x == 0) n_kept[b] = running;

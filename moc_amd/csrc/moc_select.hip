@@ -144,13 +144,22 @@ __global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a) {
     const int64_t xbase = a.x_off ? a.x_off[b] : base;
     const int nk = a.n_kept ? a.n_kept[b] : (int)(a.row_off[b + 1] - base);
     int running = 0;
-    for (int c0 = 0; c0 < nk; c0 += blockDim.x) {
-        const int i = c0 + threadIdx.x;
-        const bool f = i < nk && a.sel_flag[base + i] != 0;
+    // a thread owns 16 consecutive slots: its flags come in one batch of loads, one block scan places them
+    for (int c0 = 0; c0 < nk; c0 += 16 * 1024) {
+        const int i0 = c0 + (int)threadIdx.x * 16;
+        unsigned bits = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = i0 + q;
+            const uint8_t f = a.sel_flag[base + (i < nk ? i : nk - 1)];
+            bits |= (i < nk && f != 0 ? 1u : 0u) << q;
+        }
         int tot;
-        const int pos = moc_block_flag_scan(f, wave_tot, &tot);
-        if (f) {
-            const int64_t o = base + running + pos;
+        const int pos = moc_block_count_scan(__popc(bits), wave_tot, &tot);
+        int64_t o = base + running + pos;
+        while (bits) {                                   // ascending: lowest set bit first
+            const int i = i0 + __ffs((int)bits) - 1;
+            bits &= bits - 1;
             a.sel_idx[o] = i;
             a.sel_row[o] = xbase + (a.kept ? a.kept[base + i] : i);
             if (a.cand_inline) {                       // few columns (C <= 4): copied here, no second launch
@@ -159,6 +168,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a) {
                 for (int k = 0; k < 2 * C + 1; ++k) c[(int64_t)k * a.stride] = s[(int64_t)k * a.stride];
                 c[(int64_t)(2 * C + 1) * a.stride] = s[(int64_t)(2 * C + 2) * a.stride];   // s_beta = max background
             }
+            ++o;
         }
         running += tot;
     }
