@@ -1383,7 +1383,7 @@ int launch_pool(const moc_batch_t* B, const moc_meta_ws_t* ws, int slide0, int n
 
 int launch_finish(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels,
                   int slide0, int n, int train, int apply_adam, uint32_t use_bits, const AdamCoef& k, hipStream_t s) {
-    FinishArgs a;
+    FinishArgs a = {};
     a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel; a.cand = B->cand;
     a.H1 = ws->H1; a.gates = ws->gates; a.pooled = ws->pooled; a.topk_idx = ws->topk_idx; a.topk_cnt = ws->topk_cnt;
     a.labels = labels; a.loss = ws->loss; a.pred = ws->pred;
