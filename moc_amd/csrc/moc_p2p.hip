@@ -41,8 +41,9 @@ int moc_p2p_next_args(moc_p2p* c, P2pArgs* x) {
         MOC_REQUIRE(c->peer[q], "moc_p2p: rank %d is not connected (moc_p2p_connect)", q);
     memset(x, 0, sizeof(*x));
     x->world = c->world; x->rank = c->rank; x->n_par = c->n_par;
-    x->seq = ++c->seq;
-    if (x->seq == 0) x->seq = ++c->seq;        // 0 is "nothing pushed yet"
+    x->seq = ++c->seq;                         // starts at 1 (the flags start at 0 = "nothing pushed yet"); wraps through 0
+                                               // after 2^32 exchanges, which the signed-difference test in the kernel absorbs
+                                               // and which keeps the buffer parity alternating
     x->flags = (uint32_t*)c->local;
     x->sticky = x->flags + STICKY_WORD;
     x->recv = (float*)((char*)c->local + FLAG_BYTES);
