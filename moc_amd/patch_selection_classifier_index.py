@@ -8,7 +8,6 @@ moc_select kernel forms their union directly (moc_amd/main_moc.py).
 """
 from __future__ import annotations
 
-import ctypes as C
 
 import torch
 
