@@ -193,6 +193,23 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
                 "launches": len(ms)}
+        # the same launch with nothing else on the GPU (in the loop it shares the memory system with the previous
+        # pass's meta-steps on the main stream): the last train batch, as it stands, ten launches
+        last = (M.train.last if world == 1 and not a.force_dp else mdist.train_dp.last)[0]
+        torch.cuda.synchronize()
+        iso = []
+        for _ in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            check = engine.check
+            e0.record()
+            check(engine.lib().moc_scores(engine.C.byref(last.c), engine.ptr(M._bank_for(res.X, dev).image), engine._stream()), "moc_scores")
+            e1.record()
+            torch.cuda.synchronize()
+            iso.append(e0.elapsed_time(e1))
+        iso_ms = sorted(iso)[len(iso) // 2]
+        iso_bytes = last.kept_rows_host * D * esz
+        roof["alone"] = {"achieved": round(iso_bytes / (iso_ms * 1e-3) / 1e9, 1),
+                         "frac": round(iso_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launch_us": round(iso_ms * 1e3, 2)}
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:

@@ -246,7 +246,7 @@ def slide_process(feat, zeroshot_weights, zeroshot_weights_ext,
 PREFETCH_PHASE_A = os.environ.get("MOC_PREFETCH_PHASE_A", "1") != "0"
 
 
-def _issue_phase_a(plan, turn, bank, rng_before):
+def _issue_phase_a(plan, turn, bank, rng_before, host_wait=None):
     """Draw the masks that follow generator state `rng_before` (main_moc.py:330: same stream of bits),
     upload them and run phase A into work-array set `turn` on the CURRENT stream.
     -> generator state after the draws (None: the state's layout is unknown, torch drew and advanced itself)."""
@@ -254,6 +254,8 @@ def _issue_phase_a(plan, turn, bank, rng_before):
     if plan["stage_free"][turn] is not None:
         plan["stage_free"][turn].synchronize()          # the phase A that read that pinned buffer has run
     stage, kept, rng_after = engine.draw_row_masks_from(rng_before, batch.total, plan["stage"][turn])
+    if host_wait is not None:
+        host_wait.synchronize()                         # (after the draw: the host works while it would wait)
     batch.use_host_mask(stage, kept)                    # read in place by the compaction kernel: no upload
     batch.phase_a(plan["bank"])
     ev = torch.cuda.Event()
@@ -309,10 +311,11 @@ def resident_pass_done(res, device, args):
     mark.record(main)
     plan.setdefault("steps_done", [None, None])[turn] = mark
     before = torch.get_rng_state()
+    # The HOST waits for that mark, not the side stream: a stream-side wait on an event of the main stream
+    # cost ~45 us of GPU time per pass here (scripts/diag_overlap.py: 0.76 ms per epoch against 0.72), and
+    # the host is a pass ahead with this pass's launches already queued, so its wait starves nothing.
     with torch.cuda.stream(side):
-        if plan["steps_done"][other] is not None:
-            side.wait_event(plan["steps_done"][other])
-        after = _issue_phase_a(plan, other, bank, before)
+        after = _issue_phase_a(plan, other, bank, before, host_wait=plan["steps_done"][other])
         done = torch.cuda.Event()
         done.record(side)
     if after is None:                                   # torch drew for us and moved its generator: undo, no speculation

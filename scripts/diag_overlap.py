@@ -47,8 +47,36 @@ def run(n, do_a, do_b):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
+def run_events(n, side_waits_mark, main_waits_done, host_waits_mark=False):
+    """The pass-ahead loop's event structure, minus the host-side mask draw: A(e+1) may start when B(e-1) is
+    done; B(e+1) when A(e+1) is done."""
+    torch.cuda.synchronize()
+    marks = [None, None]
+    done = None
+    t0 = time.perf_counter()
+    for e in range(n):
+        main = torch.cuda.current_stream()
+        if main_waits_done and done is not None:
+            main.wait_event(done)
+        engine.train_steps(bB, meta, lab, 0, 32, use)
+        m = torch.cuda.Event(); m.record(main); marks[e & 1] = m
+        if host_waits_mark and marks[(e + 1) & 1] is not None:
+            marks[(e + 1) & 1].synchronize()                 # the HOST waits for B(e-1); no packet on the side stream
+        with torch.cuda.stream(side):
+            if side_waits_mark and marks[(e + 1) & 1] is not None:
+                side.wait_event(marks[(e + 1) & 1])
+            bA.phase_a(bank)
+            done = torch.cuda.Event(); done.record(side)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
 n = 40
 run(5, True, True)
 a, b, ab = run(n, True, False), run(n, False, True), run(n, True, True)
+ev_all, ev_side, ev_main = run_events(n, True, True), run_events(n, True, False), run_events(n, False, True)
+ev_host = run_events(n, False, True, host_waits_mark=True)
+print(f"host waits for the mark instead of the side stream: {ev_host:.3f} ms")
+print(f"with the loop's events: both waits {ev_all:.3f} ms, only side-waits-mark {ev_side:.3f}, only main-waits-done {ev_main:.3f}")
 print(f"per epoch: phase A alone {a:.3f} ms, phase B alone {b:.3f} ms, both on two streams {ab:.3f} ms "
       f"(sum {a + b:.3f}; hidden {100 * (a + b - ab) / a:.0f} % of phase A)")
