@@ -137,9 +137,16 @@ class ResidentBags:
                                   x_starts=[self.starts[k] for k in order]) for _ in range(2)]
             lab = torch.tensor([self.labels[k] for k in order], dtype=torch.int64).to(self.X.device)
             stage = [torch.empty(T, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            side = torch.cuda.Stream(device=self.X.device)
+            # the side stream reads X and writes the work arrays: tell the caching allocator, so that memory freed
+            # while a pass-ahead phase A is still in flight is not handed to someone else under it
+            self.X.record_stream(side)
+            for b in batches:
+                for t in (b.kept, b.n_kept, b.stats, b.sel_flag, b.sel_idx, b.sel_row, b.n_sel, b.cand, b.row_off, b.x_off):
+                    if t is not None:
+                        t.record_stream(side)
             plan = self._plans[key] = {"batch": batches[0], "batches": batches, "labels": lab, "stage": stage,
-                                       "stage_free": [None, None], "turn": 0, "ahead": None,
-                                       "side": torch.cuda.Stream(device=self.X.device)}
+                                       "stage_free": [None, None], "turn": 0, "ahead": None, "side": side}
         return plan
 
     def eval_plan(self, C_, Ce, topj, topk, discard):
