@@ -250,6 +250,121 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
     MOC_STAMP(2);
 }
 
+// Many slides at once (evaluation): 30,000 sixteen-row workgroups each re-read the whole 192 KiB W1 image and
+// the pass is bound by L2 (5.9 GB at 29 TB/s for 202 slides).  Here a workgroup owns 64 rows (four row tiles):
+// every W1 fragment a wave loads feeds four MFMAs, a quarter of the L2 traffic.  Units of 512 bytes of a row
+// (8 k-steps: 96 registers of fragments, three workgroups per CU).  Same products in the same order per
+// (row, hidden unit) as meta_forward_kernel: bit-identical outputs.  grid (ceil(S_bound/64), n); 16-bit storage.
+template <bool F16>
+__global__ __launch_bounds__(256) void meta_forward64_kernel(FwdArgs a) {
+    __shared__ __attribute__((aligned(16))) uint4 xt[64 * 32];     // 64 rows x 512 B of the current unit, chunk-swizzled
+    __shared__ float Hs[64][H + 1];
+    __shared__ float Gs[64][4];
+    __shared__ float W2s[4 * H];
+    const int b = a.slide0 + blockIdx.y;
+    const int64_t base = a.row_off[b];
+    const int S = a.n_sel[b];
+    const int row0 = blockIdx.x * 64;
+    if (row0 >= S) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    // epilogue operands that do not depend on the product first: thread -> (row, class) for C <= 4
+    float pre_c[4] = {0.f, 0.f, 0.f, 0.f};
+    if (threadIdx.x < 64 * C && row0 + (threadIdx.x & 63) < S) {
+        const int r = threadIdx.x & 63, c = threadIdx.x >> 6;
+        const float* cd = a.cand + base + row0 + r;
+        pre_c[0] = cd[(int64_t)c * a.stride];
+        pre_c[1] = cd[(int64_t)(C + c) * a.stride];
+        pre_c[2] = cd[(int64_t)(2 * C) * a.stride];
+        pre_c[3] = cd[(int64_t)(2 * C + 1) * a.stride];
+    }
+    const float w2_pre = a.W2[threadIdx.x & 255];
+    const float bias = a.b1[wave * 16 + (lane & 15)];
+    const float b2_pre = a.b2[threadIdx.x & 3];
+    const int64_t row_bytes = (int64_t)a.D * 2;
+    const int U = (int)(row_bytes / 512), KST = (int)(row_bytes / 64);
+    // wave w fetches rows 16w..16w+15 of the tile: one load = two rows x 512 B (lane l: row 2j + (l >> 5), chunk l & 31)
+    const unsigned char* rp[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int sr = min(row0 + wave * 16 + 2 * j + (lane >> 5), S - 1);
+        rp[j] = a.X + a.sel_row[base + sr] * row_bytes + (lane & 31) * 16;
+    }
+    f32x4_t acc[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < U; ++u) {
+        if (u > 0) __syncthreads();                               // every wave is done reading the previous unit
+        uint4 xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = *reinterpret_cast<const uint4*>(rp[j] + (int64_t)u * 512);
+        uint4 wv[8 * 3];
+        const uint4* wi = reinterpret_cast<const uint4*>(a.W1img) + ((size_t)wave * KST + (size_t)u * 8) * 3 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 8 * 3; ++q) wv[q] = wi[q * 64];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = wave * 16 + 2 * j + (lane >> 5);
+            xt[r * 32 + ((lane & 31) ^ (r & 15))] = xv[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const int r = rt * 16 + (lane & 15);
+                const uint4 A = xt[r * 32 + ((kk * 4 + (lane >> 4)) ^ (r & 15))];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[rt] = moc_mfma_half<F16>(A, wv[kk * 3 + t], acc[rt]);
+            }
+        }
+    }
+    {   // acc[rt][i] = pre-activation of row rt*16 + (lane>>4)*4 + i, hidden unit wave*16 + (lane&15)
+        const int hcol = wave * 16 + (lane & 15);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float pre = F16 ? acc[rt][i] * (1.f / MOC_F16_W1_SCALE) : acc[rt][i];     // exact power-of-two scaling
+                Hs[rt * 16 + (lane >> 4) * 4 + i][hcol] = fmaxf(__fadd_rn(pre, bias), 0.f);
+            }
+        W2s[threadIdx.x] = w2_pre;
+    }
+    __syncthreads();
+    if (a.H1) {                          // needed by the backward pass only: evaluation passes NULL
+        for (int e = threadIdx.x; e < 64 * H; e += 256) {
+            const int r = e >> 6, h = e & 63;
+            if (row0 + r < S) a.H1[(base + row0 + r) * H + h] = Hs[r][h];
+        }
+    }
+    {
+        const int r = threadIdx.x >> 2, i = threadIdx.x & 3;
+        float z = 0.f;
+        for (int h = 0; h < H; ++h) z = fmaf(Hs[r][h], W2s[i * H + h], z);
+        z += b2_pre;
+        const float g = 1.f / (1.f + expf(-z));
+        Gs[r][i] = g;
+        if (a.gates && row0 + r < S) a.gates[(base + row0 + r) * 4 + i] = g;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * C; e += 256) {
+        const int r = e & 63, c = e >> 6;
+        if (row0 + r >= S) continue;
+        float s0 = pre_c[0], s1 = pre_c[1], s2 = pre_c[2], s3 = pre_c[3];
+        if (e >= 256) {   // C > 4: beyond the prefetched element
+            const float* cd = a.cand + base + row0 + r;
+            s0 = cd[(int64_t)c * a.stride]; s1 = cd[(int64_t)(C + c) * a.stride];
+            s2 = cd[(int64_t)(2 * C) * a.stride]; s3 = cd[(int64_t)(2 * C + 1) * a.stride];
+        }
+        float v = 0.f;   // 0 + x == x exactly, so this is the reference's running sum in both modes
+        if (a.use_bits & 1u) v = __fadd_rn(v, __fmul_rn(Gs[r][0], s0));
+        if (a.use_bits & 2u) v = __fadd_rn(v, __fmul_rn(Gs[r][1], s1));
+        if (a.use_bits & 4u) v = __fadd_rn(v, __fmul_rn(Gs[r][2], s2));
+        if (a.use_bits & 8u) v = __fadd_rn(v, __fmul_rn(Gs[r][3], s3));
+        a.mixed[(int64_t)c * a.stride + base + row0 + r] = v;
+    }
+}
+
 // ablation mixes (main_moc.py:538-553): grid (ceil(S_bound/256), n), thread -> selected row
 __global__ __launch_bounds__(256) void fixed_mix_kernel(FwdArgs a, int mode) {
     const int b = a.slide0 + blockIdx.y;
@@ -1369,6 +1484,13 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
     a.D = B->D; a.C = B->C; a.slide0 = slide0; a.use_bits = use_bits;
     a.base_host = (n == 1 && B->row_off_host) ? B->row_off_host[slide0] : -1;
     dim3 grid(moc_cdiv(s_bound(B), 16), n);
+    if (n >= 4 && B->dtype != MOC_F32 && (B->D * 2) % 512 == 0) {       // many slides at once (evaluation)
+        dim3 g64(moc_cdiv(s_bound(B), 64), n);
+        if (B->dtype == MOC_F16) meta_forward64_kernel<true><<<g64, 256, 0, s>>>(a);
+        else meta_forward64_kernel<false><<<g64, 256, 0, s>>>(a);
+        MOC_CHECK_LAUNCH("moc_meta_forward(64)");
+        return MOC_OK;
+    }
     if (B->dtype == MOC_F16) meta_forward_kernel<true, true><<<grid, 256, 0, s>>>(a);
     else if (B->dtype == MOC_BF16) meta_forward_kernel<true><<<grid, 256, 0, s>>>(a);
     else meta_forward_kernel<false><<<grid, 256, 0, s>>>(a);

@@ -510,6 +510,39 @@ def test_full_size_properties(dev):
     assert abs(ev["loss"] - ev_ref["loss"]) < ATOL and ev["acc"] == ev_ref["acc"] and abs(ev["auc"] - ev_ref["auc"]) < 2e-3
 
 
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 512), (torch.float16, 512), (torch.bfloat16, 768), (torch.float16, 256)])
+def test_batched_forward_is_bit_identical_to_one_slide_at_a_time(dev, dtype, D):
+    """Many slides at once take the 64-row forward kernel (W1 fragments shared by four row tiles); the
+    meta-step's one-slide kernel must give the same bits: hidden layer, gates and mixed scores."""
+    M, E = _mm(), _engine()
+    C, j, K = 3, 150, 10
+    W, We = synth.make_bank(71, D, C)
+    Wd, Wed = W.to(dev), We.to(dev)
+    sizes = [900, 1500, 64, 2100, 333, 1207]
+    bags = [synth.make_bag_device(7100 + i, n, D, We, C, i % C, dev, dtype) for i, n in enumerate(sizes)]
+    torch.manual_seed(3)
+    model = M.senet(D, 4).to(dev)
+    X, _ = M._pack(bags, dev, dtype)
+    b = E.SlideBatch(X, sizes, C, C + 4, j, K)
+    b.phase_a(E.Bank.get(Wd, Wed, dtype, dev))
+    meta = E.MetaState(model)
+    t = b.meta_ws()[0]
+    E.meta_forward(b, meta, 0, len(sizes), 15)
+    torch.cuda.synchronize()
+    together = {k: t[k].clone() for k in ("mixed", "H1", "gates")}
+    for k in together:
+        t[k].zero_()
+    for i in range(len(sizes)):
+        E.meta_forward(b, meta, i, 1, 15)
+    torch.cuda.synchronize()
+    ns = b.n_sel.cpu().tolist()
+    for i, n in enumerate(ns):
+        o = b.row_off_host[i]
+        assert torch.equal(together["mixed"][:, o:o + n], t["mixed"][:, o:o + n])
+        assert torch.equal(together["H1"][o:o + n], t["H1"][o:o + n])
+        assert torch.equal(together["gates"][o:o + n], t["gates"][o:o + n])
+
+
 # ------------------------------------------------------------------ paths the fixtures do not reach
 @pytest.mark.parametrize("C,K,j,D,dtype,sizes", [
     (2, 20, 100, 512, torch.float32, [900, 700, 1100]),        # K > 16: general pooling + step kernels
