@@ -40,3 +40,18 @@ gp = []
 for _ in range(10):
     torch.cuda.synchronize(); s.record(); M.evaluation(model, res, dev, args); e.record(); torch.cuda.synchronize(); gp.append(s.elapsed_time(e) * 1e3)
 print(f"GPU span of a pass (first launch -> D2H done): median {sorted(gp)[5]:.0f} us")
+# host time to queue a pass (no wait for the GPU): everything before the device->host copy
+import torch as _t
+orig_cat = _t.cat
+marks = []
+def cat_mark(ts, dim=0):
+    r = orig_cat(ts, dim)
+    if r.is_cuda and r.dim() == 2 and r.size(0) == n:
+        marks.append(time.perf_counter())
+    return r
+_t.cat = cat_mark
+M._eval_pass = orig_pass
+q = []
+for _ in range(10):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); M.evaluation(model, res, dev, args); q.append((marks[-1] - t0) * 1e6)
+print(f"host time to queue a pass: median {sorted(q)[5]:.0f} us")
