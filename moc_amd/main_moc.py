@@ -387,6 +387,19 @@ def _auc(y_true: np.ndarray, y_score: np.ndarray) -> float:
         return _binary_auc(y_true == classes[1], y_score)
     if classes.size != y_score.shape[1] or classes.size < 2 or not np.array_equal(classes, np.arange(classes.size)):
         return roc_auc_score(y_true, y_score, multi_class="ovo", average="macro")
+    n, Cn = y_score.shape
+    if n <= 4 * Cn * (Cn - 1):        # n^2 comparisons against C (C - 1) sorts of ~2n/C values: many classes, few slides
+        # every pair at once.  G[i, j] = [p[i, y_i] > p[j, y_i]] + [==] / 2; U[a, b] = sum of G over i in a, j in b
+        # = n_a n_b x the AUC of class a against class b on column a (Mann-Whitney, ties at one half).  Sums of
+        # multiples of 1/2: exact.  (np.bincount, not a matrix product: BLAS starts a thread per visible core.)
+        own = y_score[np.arange(n), y_true]
+        cols = y_score[:, y_true].T
+        G = (own[:, None] > cols) + 0.5 * (own[:, None] == cols)
+        pair = (y_true[:, None] * Cn + y_true[None, :]).ravel()
+        U = np.bincount(pair, weights=G.ravel(), minlength=Cn * Cn).reshape(Cn, Cn)
+        cnt = np.bincount(y_true, minlength=Cn).astype(np.float64)
+        A = U / np.outer(cnt, cnt)
+        return float((A.sum() - np.trace(A)) / (Cn * (Cn - 1)))
     masks = [y_true == c for c in classes]
     total, n_pairs = 0.0, 0
     for a in range(classes.size):
