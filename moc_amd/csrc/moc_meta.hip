@@ -268,15 +268,25 @@ __global__ __launch_bounds__(256) void meta_forward64_kernel(FwdArgs a) {
     if (row0 >= S) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = a.C;
-    // epilogue operands that do not depend on the product first: thread -> (row, class) for C <= 4
-    float pre_c[4] = {0.f, 0.f, 0.f, 0.f};
-    if (threadIdx.x < 64 * C && row0 + (threadIdx.x & 63) < S) {
-        const int r = threadIdx.x & 63, c = threadIdx.x >> 6;
-        const float* cd = a.cand + base + row0 + r;
-        pre_c[0] = cd[(int64_t)c * a.stride];
-        pre_c[1] = cd[(int64_t)(C + c) * a.stride];
-        pre_c[2] = cd[(int64_t)(2 * C) * a.stride];
-        pre_c[3] = cd[(int64_t)(2 * C + 1) * a.stride];
+    // Epilogue operands do not depend on the product: requested first.  Thread -> row tid & 63 (the same row in
+    // every round), classes (tid >> 6) + 4 it: the two per-row scores once, the per-class pairs of the first
+    // 32 classes here (later chunks of 32 are requested a chunk at a time, all loads before the first store).
+    const int er = threadIdx.x & 63, ec0 = threadIdx.x >> 6;
+    const bool erow_ok = row0 + er < S;
+    const float* ecd = a.cand + base + row0 + er;
+    float es2 = 0.f, es3 = 0.f, es0[8], es1[8];
+    if (erow_ok) {
+        es2 = ecd[(int64_t)(2 * C) * a.stride];
+        es3 = ecd[(int64_t)(2 * C + 1) * a.stride];
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int c = ec0 + 4 * it;
+        es0[it] = es1[it] = 0.f;
+        if (erow_ok && c < C) {
+            es0[it] = ecd[(int64_t)c * a.stride];
+            es1[it] = ecd[(int64_t)(C + c) * a.stride];
+        }
     }
     const float w2_pre = a.W2[threadIdx.x & 255];
     const float bias = a.b1[wave * 16 + (lane & 15)];
@@ -347,21 +357,28 @@ __global__ __launch_bounds__(256) void meta_forward64_kernel(FwdArgs a) {
         if (a.gates && row0 + r < S) a.gates[(base + row0 + r) * 4 + i] = g;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 64 * C; e += 256) {
-        const int r = e & 63, c = e >> 6;
-        if (row0 + r >= S) continue;
-        float s0 = pre_c[0], s1 = pre_c[1], s2 = pre_c[2], s3 = pre_c[3];
-        if (e >= 256) {   // C > 4: beyond the prefetched element
-            const float* cd = a.cand + base + row0 + r;
-            s0 = cd[(int64_t)c * a.stride]; s1 = cd[(int64_t)(C + c) * a.stride];
-            s2 = cd[(int64_t)(2 * C) * a.stride]; s3 = cd[(int64_t)(2 * C + 1) * a.stride];
+    for (int cb = 0; cb < C; cb += 32) {
+        if (cb > 0) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int c = cb + ec0 + 4 * it;
+                if (erow_ok && c < C) {
+                    es0[it] = ecd[(int64_t)c * a.stride];
+                    es1[it] = ecd[(int64_t)(C + c) * a.stride];
+                }
+            }
         }
-        float v = 0.f;   // 0 + x == x exactly, so this is the reference's running sum in both modes
-        if (a.use_bits & 1u) v = __fadd_rn(v, __fmul_rn(Gs[r][0], s0));
-        if (a.use_bits & 2u) v = __fadd_rn(v, __fmul_rn(Gs[r][1], s1));
-        if (a.use_bits & 4u) v = __fadd_rn(v, __fmul_rn(Gs[r][2], s2));
-        if (a.use_bits & 8u) v = __fadd_rn(v, __fmul_rn(Gs[r][3], s3));
-        a.mixed[(int64_t)c * a.stride + base + row0 + r] = v;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int c = cb + ec0 + 4 * it;
+            if (!erow_ok || c >= C) continue;
+            float v = 0.f;   // 0 + x == x exactly, so this is the reference's running sum in both modes
+            if (a.use_bits & 1u) v = __fadd_rn(v, __fmul_rn(Gs[er][0], es0[it]));
+            if (a.use_bits & 2u) v = __fadd_rn(v, __fmul_rn(Gs[er][1], es1[it]));
+            if (a.use_bits & 4u) v = __fadd_rn(v, __fmul_rn(Gs[er][2], es2));
+            if (a.use_bits & 8u) v = __fadd_rn(v, __fmul_rn(Gs[er][3], es3));
+            a.mixed[(int64_t)c * a.stride + base + row0 + er] = v;
+        }
     }
 }
 
