@@ -24,7 +24,10 @@ import sys
 import time
 import types
 
-import torch
+# dmabuf IPC (peer-mapped exchange buffers, RCCL): must be in the environment before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
