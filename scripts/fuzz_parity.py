@@ -20,6 +20,24 @@ from moc_amd import main_moc as M, synth  # noqa: E402
 from oracle import moc_oracle as O  # noqa: E402
 
 
+class NearTie(Exception):
+    pass
+
+
+def boundary_margin(x, W, We, C, j):
+    """Smallest gap between the j-th and (j+1)-th key over the 2C+2 selector columns of one masked slide."""
+    lg, le = x @ W, x @ We
+    cols = [lg[:, c] for c in range(C)] + [c_ for c_ in torch.softmax(lg, 1).T]
+    t2 = lg.topk(min(2, C), 1).values
+    cols += [(t2[:, 0] - t2[:, -1]).abs(), -le[:, C:].sum(1)]
+    gap = float("inf")
+    for v in cols:
+        s = v.sort(descending=True).values
+        if j < s.numel():
+            gap = min(gap, float(s[j - 1] - s[j]))
+    return gap
+
+
 def one_case(rng, dev, idx):
     C = int(rng.choice([2, 2, 3, 4, 5, 8, 12, 16, 20, 30, 40]))
     D = int(rng.choice([256, 512, 512, 768, 1024]))
@@ -54,7 +72,17 @@ def one_case(rng, dev, idx):
         torch.manual_seed(seed + 1 + epoch)
         M.train(model, res, opt, dev, args)
         got = M.train.last[0].meta_ws()[0]["loss"].cpu().numpy()
-        np.testing.assert_allclose(got, np.asarray(ref_losses), atol=1e-4, err_msg=desc)
+        try:
+            np.testing.assert_allclose(got, np.asarray(ref_losses), atol=1e-4, err_msg=desc)
+        except AssertionError:
+            # A selector whose j-th and (j+1)-th keys tie (or nearly: softmax columns at 12+ classes do, exactly) has
+            # no defined winner -- torch.topk's pick among equal keys is unspecified and the keys themselves differ in
+            # the last bit between the CPU's and the GPU's exp.  Such a case says nothing about parity.
+            torch.manual_seed(seed + 1 + epoch)
+            gap = min(boundary_margin(x[O.draw_mask(x.size(0))], W, We, C, j) for x in ref_bags)
+            if gap < 1e-6:
+                raise NearTie(f"{desc}: selection boundary margin {gap:.1e}")
+            raise
     H.assert_adam_params_close(H.flat_params(model), H.flat_params(ref_model), H.flat_state(ref_opt, "exp_avg_sq"),
                                step=2 * len(sizes), grad_noise=1e-6, what=desc)
     if len(set(labels)) == C:                                  # AUC needs every class present
@@ -72,16 +100,20 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(a.seed)
-    bad = 0
+    bad = ties = 0
     t0 = time.time()
     for i in range(a.cases):
         try:
             desc = one_case(rng, dev, i)
             print("ok  ", desc, flush=True)
+        except NearTie as e:
+            ties += 1
+            print("TIE ", str(e), flush=True)
         except AssertionError as e:
             bad += 1
             print("FAIL", str(e)[:1500], flush=True)
-    print(f"{a.cases - bad}/{a.cases} cases agree with the oracle ({time.time() - t0:.0f} s)")
+    print(f"{a.cases - bad - ties}/{a.cases - ties} cases agree with the oracle ({time.time() - t0:.0f} s); "
+          f"{ties} set aside: a selector's j-th key tied with the next")
     sys.exit(1 if bad else 0)
 
 
