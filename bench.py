@@ -73,6 +73,11 @@ def parse():
 
 def main():
     a = parse()
+    # stdout carries the ONE JSON line and nothing else: whatever libraries print there (librccl announces its
+    # path on stdout when a communicator is created) goes to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -314,7 +319,8 @@ def main():
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or a.force_dp:
         mdist.shutdown()
         dist.destroy_process_group()
