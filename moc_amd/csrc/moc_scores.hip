@@ -546,16 +546,20 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
 // reads of the loop are hand-issued with counted waits (an ordinary LDS read makes hipcc wait vmcnt(0)
 // first -- the DMA in flight writes LDS too -- which would serialise DMA and MFMA).
 constexpr int WD_R = 4;               // row tiles per wave
-constexpr int WD_KC = 2;              // k-steps (of 32 columns) per chunk
+// k-steps (of 32 columns) per chunk: up to 6 n-tiles one k-step per chunk and TWO workgroups per CU (62 KiB of LDS
+// and at most 246 registers each: one's DMA waits and row epilogues run beside the other's MFMAs, +12 % at
+// 5 n-tiles); wider banks need the registers of a whole SIMD and take two k-steps per chunk
+constexpr int wd_kc(int NT) { return NT <= 6 ? 1 : 2; }
 
 template <int NT, bool F16>
-__global__ __launch_bounds__(256, 1) void scores_wide_kernel(ScoresArgs a) {
+__global__ __launch_bounds__(256, (NT <= 6 ? 2 : 1)) void scores_wide_kernel(ScoresArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WD_KC = wd_kc(NT);
     constexpr int B_BYTES = NT * WD_KC * 3 * 1024;                  // image slice of one chunk
     constexpr int A_BYTES = 4 * WD_R * WD_KC * 1024;                // 4 waves x R row tiles x KC k-steps x 1 KiB
     constexpr int BUF = B_BYTES + A_BYTES;
     constexpr int LDT = NT * 16 + 1;
-    float* tile = reinterpret_cast<float*>(smem + 2 * BUF) + (threadIdx.x >> 6) * 16 * LDT;
+    float* tile = reinterpret_cast<float*>(smem) + (threadIdx.x >> 6) * 16 * LDT;      // (the epilogue's tiles reuse the chunk buffers)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int64_t base = a.row_off[b];
@@ -830,8 +834,10 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
     }
     // wide banks on 16-bit storage: the K-split form (every bag row read once)
     if (bf && a.NT >= 4 && a.NT <= 8 && B->D % 64 == 0) {
-        const size_t buf = (size_t)a.NT * WD_KC * 3 * 1024 + (size_t)4 * WD_R * WD_KC * 1024;
-        const size_t smem_w = 2 * buf + (size_t)4 * 16 * (a.NT * 16 + 1) * sizeof(float);
+        const size_t kc = wd_kc(a.NT);
+        const size_t buf = (size_t)a.NT * kc * 3 * 1024 + (size_t)4 * WD_R * kc * 1024;
+        const size_t tiles = (size_t)4 * 16 * (a.NT * 16 + 1) * sizeof(float);
+        const size_t smem_w = 2 * buf > tiles ? 2 * buf : tiles;
         dim3 grid_w(moc_cdiv(B->max_rows, 4 * WD_R * 16), B->n_slides);
 #define MOC_LAUNCH_WIDE(NTT)                                                                            \
         do {                                                                                            \
@@ -844,7 +850,7 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
             if (f16) scores_wide_kernel<NTT, true><<<grid_w, 256, smem_w, s>>>(a);                      \
             else scores_wide_kernel<NTT, false><<<grid_w, 256, smem_w, s>>>(a);                         \
         } while (0)
-        if (smem_w <= 160 * 1024) {
+        if (smem_w < 160 * 1024) {
             switch (a.NT) {
                 case 4: MOC_LAUNCH_WIDE(4); break;
                 case 5: MOC_LAUNCH_WIDE(5); break;
