@@ -133,6 +133,26 @@ __device__ __forceinline__ int moc_block_count_scan(int cnt, int* wave_tot, int*
     return off + inc - cnt;
 }
 
+// inclusive max-scan by DPP row shifts, then the wave total from lane 63 (gfx9 DPP controls:
+// row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#define MOC_DPP_STEP(ctrl, rmask)                                                                  \
+    {                                                                                              \
+        const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, ctrl, rmask, 0xf, false); \
+        const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, ctrl, rmask, 0xf, false); \
+        const bool gt = ohi > hi || (ohi == hi && olo > lo);                                       \
+        lo = gt ? olo : lo;                                                                        \
+        hi = gt ? ohi : hi;                                                                        \
+    }
+    MOC_DPP_STEP(0x111, 0xf) MOC_DPP_STEP(0x112, 0xf) MOC_DPP_STEP(0x114, 0xf) MOC_DPP_STEP(0x118, 0xf)
+    MOC_DPP_STEP(0x142, 0xa) MOC_DPP_STEP(0x143, 0xc)
+#undef MOC_DPP_STEP
+    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // ---- diagnostic build only (-DMOC_STAMPS, make stamps): constant-clock (100 MHz) time stamps of
 // kernel phases, written by thread 0 of workgroup (0,0) to a global array that nothing else reads.
 #ifdef MOC_STAMPS

@@ -208,6 +208,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(CompactArgs a) {
 }
 
 // ---- generic top-K mean ------------------------------------------------------
+constexpr int TK_CAND = 1024;      // candidate list of topk_mean_kernel's K <= 16 path
+
 struct TopkArgs {
     const float* keys;
     const float* vals;
@@ -251,11 +253,68 @@ __global__ __launch_bounds__(1024) void topk_mean_kernel(TopkArgs a) {
     unsigned long long* list = reinterpret_cast<unsigned long long*>(smem);   // (key << 32) | ~row : descending
     if (threadIdx.x == 0) n_list = 0;
     for (int i = threadIdx.x; i < P; i += blockDim.x) list[i] = 0ull;
+    // ---- K <= 16: no radix passes.  The k-th largest of the 16 per-wave maxima is a lower bound T0 of the k-th
+    // largest key (k waves hold a key >= T0), so only keys >= T0 can be in the top k -- typically a few dozen of
+    // thousands.  They go to an LDS list (TK_CAND entries) and one wave extracts the k largest in order, ties by
+    // ascending row: the same list the radix path ends with, after two sweeps over the keys instead of five.
+    // Too many candidates (flat key distributions, fewer than k waves with a key): the radix path below.
+    bool done = false;                                                  // block-uniform
+    if (a.K <= 16 && k < n) {
+        unsigned long long* cand = reinterpret_cast<unsigned long long*>(((uintptr_t)(hist + 288) + 7) & ~(uintptr_t)7);   // [TK_CAND]
+        int* wmax_s = wave_tot;                                         // [16] per-wave maxima, then [16] = T0
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t mx = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) { const uint32_t u = keyfn(i); mx = u > mx ? u : mx; }
+        mx = (uint32_t)(wave_max_u64((unsigned long long)mx));
+        if (lane == 0) wmax_s[wave] = (int)mx;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            const uint32_t v = (uint32_t)wmax_s[threadIdx.x];
+            int rank = 0;
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t o = (uint32_t)wmax_s[j];
+                rank += (o > v || (o == v && j < (int)threadIdx.x)) ? 1 : 0;
+            }
+            if (rank == k - 1) wmax_s[16] = (int)v;
+        }
+        __syncthreads();
+        const uint32_t T0 = (uint32_t)wmax_s[16];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t u = keyfn(i);
+            if (u >= T0) {
+                const int pos = atomicAdd(&n_list, 1);
+                if (pos < TK_CAND) cand[pos] = ((unsigned long long)u << 32) | (uint32_t)(~(uint32_t)i);
+            }
+        }
+        __syncthreads();
+        const int nc = n_list;
+        __syncthreads();
+        if (nc <= TK_CAND) {                                            // (nc >= k: k waves contributed)
+            if (wave == 0) {
+                unsigned long long mine[TK_CAND / 64];
+#pragma unroll
+                for (int q = 0; q < TK_CAND / 64; ++q) mine[q] = q * 64 + lane < nc ? cand[q * 64 + lane] : 0ull;
+                for (int r = 0; r < k; ++r) {
+                    unsigned long long best = 0ull;
+#pragma unroll
+                    for (int q = 0; q < TK_CAND / 64; ++q) best = mine[q] > best ? mine[q] : best;
+                    best = wave_max_u64(best);                          // keys are distinct (row in the low word)
+#pragma unroll
+                    for (int q = 0; q < TK_CAND / 64; ++q) mine[q] = mine[q] == best ? 0ull : mine[q];
+                    if (lane == 0) list[r] = best;
+                }
+            }
+            done = true;
+        } else if (threadIdx.x == 0) n_list = 0;
+        __syncthreads();
+    }
     int take = 0, ties = 0;
     uint32_t T = 0;
-    if (k < n) T = block_radix_select(keyfn, n, k, hist, &take, &ties);
+    if (done) {
+    } else if (k < n) T = block_radix_select(keyfn, n, k, hist, &take, &ties);
     else __syncthreads();
-    if (k == n || take == ties) {
+    if (done) {
+    } else if (k == n || take == ties) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const uint32_t u = keyfn(i);
             if (k == n || u >= T) list[atomicAdd(&n_list, 1)] = ((unsigned long long)u << 32) | (uint32_t)(~(uint32_t)i);
@@ -275,7 +334,7 @@ __global__ __launch_bounds__(1024) void topk_mean_kernel(TopkArgs a) {
     }
     __syncthreads();
     // bitonic sort, descending (key desc, then row asc); padding zeros sink to the end
-    for (int size = 2; size <= P; size <<= 1) {
+    for (int size = 2; size <= P && !done; size <<= 1) {
         for (int st = size >> 1; st > 0; st >>= 1) {
             for (int i = threadIdx.x; i < P; i += blockDim.x) {
                 const int jx = i ^ st;
@@ -366,7 +425,7 @@ int moc_launch_topk_mean(const float* keys, int64_t key_stride, const float* val
     int P = 1;
     while (P < K) P <<= 1;
     // 1024 threads: the select passes are chains of dependent key reads, one per blockDim.x keys
-    topk_mean_kernel<<<dim3(C, n_seg), 1024, (size_t)P * 12 + 288 * sizeof(int), s>>>(a);
+    topk_mean_kernel<<<dim3(C, n_seg), 1024, (size_t)P * 12 + 288 * sizeof(int) + (K <= 16 ? 96 + TK_CAND * 8 : 0), s>>>(a);
     MOC_CHECK_LAUNCH("moc_topk_mean");
     return MOC_OK;
 }
