@@ -69,6 +69,8 @@ __device__ __forceinline__ uint32_t block_radix_select(KeyFn keyfn, int n, int w
     return prefix;
 }
 
+constexpr int SEL_CAND = 4096;     // candidate list of select_kernel's two-sweep path
+
 struct SelectArgs {
     const float* stats;
     const int64_t* row_off;
@@ -99,6 +101,41 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
     const uint32_t flip = sel == 3 ? 0xFFFFFFFFu : 0u;
     auto keyfn = [&](int i) { return moc_key_desc(col[i]) ^ flip; };
     int take, ties;
+    // ---- topj <= 1024: the topj-th largest of the 1024 per-thread maxima is a lower bound T0 of the topj-th largest
+    // key (topj threads hold a key >= T0), so only keys >= T0 can be selected: a few hundred of 15,000.  They go to
+    // an LDS list and the exact select runs on the list (and on the 1024 maxima) instead of on the column: two
+    // sweeps over the keys instead of five.  Overflowing lists and ties that straddle the boundary (ascending-row
+    // order needs the column order) take the general path below.
+    if (a.topj <= 1024 && nk > 2048) {
+        __shared__ uint32_t tmax[1024];
+        __shared__ unsigned long long cand[SEL_CAND];
+        __shared__ int n_cand;
+        uint32_t mx = 0;
+        for (int i = threadIdx.x; i < nk; i += 1024) { const uint32_t u = keyfn(i); mx = u > mx ? u : mx; }
+        tmax[threadIdx.x] = mx;
+        if (threadIdx.x == 0) n_cand = 0;
+        __syncthreads();
+        int t_take, t_ties;
+        const uint32_t T0 = block_radix_select([&](int i) { return tmax[i]; }, 1024, a.topj, hist, &t_take, &t_ties);
+        for (int i = threadIdx.x; i < nk; i += 1024) {
+            const uint32_t u = keyfn(i);
+            if (u >= T0) {
+                const int pos = atomicAdd(&n_cand, 1);
+                if (pos < SEL_CAND) cand[pos] = ((unsigned long long)u << 32) | (uint32_t)i;
+            }
+        }
+        __syncthreads();
+        const int nc = n_cand;
+        if (nc <= SEL_CAND) {                                           // block-uniform; nc >= topj
+            const uint32_t T = block_radix_select([&](int i) { return (uint32_t)(cand[i] >> 32); }, nc, a.topj, hist, &take, &ties);
+            if (take == ties) {
+                for (int i = threadIdx.x; i < nc; i += 1024)
+                    if ((uint32_t)(cand[i] >> 32) >= T) flag[(uint32_t)cand[i]] = 1;
+                return;
+            }
+        }
+        __syncthreads();
+    }
     const uint32_t T = block_radix_select(keyfn, nk, a.topj, hist, &take, &ties);
     if (take == ties) {
         for (int i = threadIdx.x; i < nk; i += blockDim.x)
