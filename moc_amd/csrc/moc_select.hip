@@ -199,17 +199,30 @@ __global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a) {
             bits &= bits - 1;
             a.sel_idx[o] = i;
             a.sel_row[o] = xbase + (a.kept ? a.kept[base + i] : i);
-            if (a.cand_inline) {                       // few columns (C <= 4): copied here, no second launch
-                const float* s = a.stats + base + i;
-                float* c = a.cand + o;
-                for (int k = 0; k < 2 * C + 1; ++k) c[(int64_t)k * a.stride] = s[(int64_t)k * a.stride];
-                c[(int64_t)(2 * C + 1) * a.stride] = s[(int64_t)(2 * C + 2) * a.stride];   // s_beta = max background
-            }
             ++o;
         }
         running += tot;
     }
     if (threadIdx.x == 0) a.n_sel[b] = running;
+    if (a.cand_inline) {
+        // Few columns (C <= 4): the candidate columns are copied here, no second launch -- as a phase of its own,
+        // one selected slot per thread: every load independent of the others and the stores coalesced (inside the
+        // loop above a thread with five selected rows walked five dependent rounds of 2C + 2 scattered loads).
+        __threadfence_block();
+        __syncthreads();                                   // the slide's sel_idx, written by this workgroup, is visible
+        for (int o = threadIdx.x; o < running; o += 1024) {
+            const int i = a.sel_idx[base + o];
+            const float* s = a.stats + base + i;
+            float* c = a.cand + base + o;
+            float v[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k)
+                if (k < 2 * C + 2) v[k] = s[(int64_t)(k == 2 * C + 1 ? 2 * C + 2 : k) * a.stride];   // the last one is s_beta = max background
+#pragma unroll
+            for (int k = 0; k < 10; ++k)
+                if (k < 2 * C + 2) c[(int64_t)k * a.stride] = v[k];
+        }
+    }
 }
 
 // grid (ceil(max_rows / 256), ceil((2C+2) / CAND_COLS), n_slides): candidate columns of the selected rows,
