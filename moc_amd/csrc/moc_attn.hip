@@ -146,11 +146,15 @@ __device__ __forceinline__ float gate_fn(float x, float y) {
     return (e - 1.f) * __frcp_rn((e + 1.f) * (1.f + f));
 }
 
-// vmcnt bookkeeping of one wave (loads complete in order).  Issue order: prologue A(0) A(1) B(0..3); slab t:
-// A(t+2), then per chunk g: B(g+4).  A = 2 instructions, B = 6.
-//   chunk g waits for B(g+1) (read into registers one chunk ahead): behind it B(g+2..g+4) = 18 (+2 when an A
-//   issue lies between: vmcnt(18) then also asks for the first third of B(g+2), issued two chunks ago);
-//   the barrier that ends slab t publishes A(t+2)'s predecessor A(t+1)... see the loop.
+// vmcnt bookkeeping of one wave (loads complete in order).  Issue order: prologue A(0) A(1) B(0..3); then, slab t:
+// A(t+2), and per chunk g: B(g+4).  A = 2 instructions (this wave's 16 rows of a slab), B = 6 (a chunk).
+//   * chunk g waits for B(g+1), which it reads into registers one chunk ahead of its use: behind B(g+1) only
+//     B(g+2..g+4) = 18 instructions may remain outstanding (+2 when an A issue lies between: vmcnt(18) then also
+//     asks for the first third of B(g+2), issued two chunks ago -- stricter, never wrong);
+//   * slab t+1 reads the raw rows A(t+2) of EVERY wave at its first chunk: behind A(t+2), issued at the start of
+//     slab t, follow 6 CH instructions, so the barrier that ends slab t waits vmcnt(min(6 CH, 18)) first;
+//   * the tail re-fetches chunks and slabs nobody reads (wrapped indices): the counts stay the same to the end,
+//     and the final barrier drains them (vmcnt(0)) before the ring is reused by the epilogue.
 template <int ND>
 __global__ __launch_bounds__(256, 1) void gated_attention_kernel(AttnArgs a) {
     constexpr int CH = ND / 4;                                        // chunks per slab = (a, b) tile pairs per wave
