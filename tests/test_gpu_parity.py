@@ -281,6 +281,51 @@ def test_topk_mean_edges(dev):
     assert torch.equal(idx[0].cpu().long(), ref[1])
 
 
+@pytest.mark.parametrize("n,K", [(70, 16), (1000, 10), (5000, 10), (16384, 16), (40000, 3), (5000, 1)])
+def test_topk_mean_small_k_paths(dev, n, K):
+    """K <= 16 takes the per-wave-maxima bound and an LDS candidate list: few waves with a key (n < 64 K: every
+    key is a candidate), ordinary columns, heavy ties (rows in ascending order among equals) and columns of ONE
+    value (the list overflows: radix path) must all give the (value desc, row asc) order."""
+    E = _engine()
+    g = torch.Generator().manual_seed(n * 31 + K)
+    cols = torch.stack([torch.randn(n, generator=g),                       # distinct values
+                        (torch.arange(n) % 5).float(),                     # heavy ties
+                        torch.full((n,), 0.25),                            # one value: everything ties
+                        -torch.arange(n).float()])                         # descending: the first K rows
+    pooled, idx, cnt = E.topk_mean(cols.to(dev), cols.to(dev), K, want_idx=True)
+    for c in range(cols.size(0)):
+        order = sorted(range(n), key=lambda i: (-float(cols[c, i]), i))[:K]
+        assert idx[0, c].tolist() == order, (c, idx[0, c].tolist()[:6], order[:6])
+        assert abs(float(pooled[0, c]) - float(cols[c, order].double().mean())) < 1e-5 and int(cnt[0, c]) == K
+    lo = E.topk_mean(cols.to(dev), cols.to(dev), K, smallest=True)
+    for c in range(cols.size(0)):
+        assert abs(float(lo[0, c]) - float(cols[c].sort().values[:K].double().mean())) < 1e-5
+
+
+@pytest.mark.parametrize("N,j", [(2049, 400), (6000, 400), (6000, 1024), (30000, 1000), (6000, 1500)])
+def test_select_candidate_path_edges(dev, N, j):
+    """topj <= 1024 on more than 2048 rows runs the exact select on the keys above the topj-th largest per-thread
+    maximum: columns of one value (list overflow), ties across the boundary (column order needed) and topj just
+    beyond the path's limit must all give the reference's sets (ties: lowest rows first)."""
+    E = _engine()
+    C = 2
+    g = torch.Generator().manual_seed(N + j)
+    lge = torch.zeros(N, C + 4)
+    lge[:, 0] = torch.randn(N, generator=g)                                # distinct values
+    lge[:, 1] = (torch.arange(N) % 3).float()                              # ties across the boundary
+    lge[:, 2:] = 0.5                                                       # psi_beta: one value everywhere
+    batch = E.SlideBatch(torch.zeros(N, 256, device=dev), [N], C, C + 4, j, 10, ["delta_softmax", "delta_diff"])
+    batch.stats.copy_(_stats_from_logits_ext(lge, C))
+    batch.sel_flag.zero_()
+    batch.select()
+    batch.gather_candidates()
+    got = set(batch.sel_idx[: int(batch.n_sel.item())].cpu().tolist())
+    exp = set(range(j))                                                    # psi_beta: all equal -> the first j rows
+    for c in range(C):
+        exp.update(sorted(range(N), key=lambda i: (-float(lge[i, c]), i))[:j])
+    assert got == exp
+
+
 # ------------------------------------------------------------------ train steps
 def _run_train_case(dev, bags, labels, masks, W, We, C, j, K, discard, model_seed, dtype=torch.float32):
     M, E = _mm(), _engine()
