@@ -30,6 +30,14 @@ def test_library_exports_every_declared_symbol():
     assert h.moc_version() == _lib.ABI_VERSION
 
 
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md section 4 maps each declared entry point to what it replaces in the reference."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in declared_symbols() if n not in doc and not n.startswith("moc_p2p_")]
+    assert not missing, f"INTEGRATION.md does not mention {missing}"
+    assert "moc_p2p_" in doc
+
+
 def test_struct_layout_matches_c_compiler(tmp_path):
     from moc_amd import _lib
     prog = tmp_path / "layout.c"
