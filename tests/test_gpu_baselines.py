@@ -52,7 +52,8 @@ def test_topk_mean_pool_gradient_is_the_gather_gradient(gpu_device):
 
 # ---------------------------------------------------------------- row f4: gated-attention pooling kernel
 @pytest.mark.parametrize("N,L,D,K", [(1, 512, 256, 1), (63, 512, 256, 1), (64, 512, 384, 3), (1000, 512, 384, 1),
-                                     (4097, 1024, 128, 2), (15000, 512, 384, 1), (777, 64, 256, 5)])
+                                     (4097, 1024, 128, 2), (15000, 512, 384, 1), (777, 64, 256, 5),
+                                     (300, 512, 256, 64), (65, 48, 128, 33), (1, 16, 128, 1)])      # K up to 64; L % 32 == 16; one row
 def test_gated_attention_pool_matches_restatement(gpu_device, N, L, D, K):
     from moc_amd import engine
     from oracle import baselines_oracle as BO
