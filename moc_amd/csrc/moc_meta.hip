@@ -1174,10 +1174,22 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     __syncthreads();
     // ---- pairs
     const int P = C * k;
+    for (int p = t; p < 2 * P; p += 1024) mask[p] = 0u;
+    // the pairs' hidden rows are requested here, with the pair operands (both hang on topk_s only): their ReLU bits
+    // are ORed into the masks after the barrier below
+    float4 hv_pre[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int e = t + q * 1024;
+        hv_pre[q] = float4{0.f, 0.f, 0.f, 0.f};
+        if (e < P * 16) {
+            const int p = e >> 4, c = p / k;
+            hv_pre[q] = *reinterpret_cast<const float4*>(a.H1 + (base + topk_s[c * K + (p - c * k)]) * H + (e & 15) * 4);
+        }
+    }
     for (int p = t; p < P; p += 1024) {
         const int c = p / k, sidx = topk_s[c * K + (p - c * k)];
         sidx_s[p] = sidx;
-        mask[2 * p] = 0u; mask[2 * p + 1] = 0u;
         prow_s[p] = a.sel_row[base + sidx];
         const float* cd = a.cand + base + sidx;
         const float sc[4] = {cd[(int64_t)c * a.stride], cd[(int64_t)(C + c) * a.stride],
@@ -1191,13 +1203,17 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     }
     __syncthreads();
     // hidden rows of the pairs: ReLU mask (64 bits) and the four values this workgroup owns
-    for (int e = t; e < P * 16; e += 1024) {
+    auto take_hidden = [&](int e, const float4& hv) {
         const int p = e >> 4, v = e & 15;
-        const float4 hv = *reinterpret_cast<const float4*>(a.H1 + (base + sidx_s[p]) * H + v * 4);
         const unsigned bits = (hv.x > 0.f ? 1u : 0u) | (hv.y > 0.f ? 2u : 0u) | (hv.z > 0.f ? 4u : 0u) | (hv.w > 0.f ? 8u : 0u);
         if (bits) atomicOr(&mask[2 * p + (v >> 3)], bits << ((v & 7) * 4));
         if (v == wg) *reinterpret_cast<float4*>(h1o + p * 4) = hv;
-    }
+    };
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+        if (t + q * 1024 < P * 16) take_hidden(t + q * 1024, hv_pre[q]);
+    for (int e = t + 5 * 1024; e < P * 16; e += 1024)           // more than 320 pairs
+        take_hidden(e, *reinterpret_cast<const float4*>(a.H1 + (base + sidx_s[e >> 4]) * H + (e & 15) * 4));
     __syncthreads();                                       // masks complete
     // ---- W1 gradient: dW1[h][d] = sum_p dh[p][h] x[p][d], pairs in chunks of WD_PCH through `region`:
     // [PCH][DS] pieces of the pairs' rows as stored + [PCH][64] fp32 dh, then v_mfma_f32_16x16x4_f32 over p
