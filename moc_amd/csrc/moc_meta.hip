@@ -17,6 +17,7 @@
 //   -> finish (1 workgroup: CE, pair gradients, Adam on b1/W2/b2)
 //   -> w1_update (W1 gradient from <= K*C gathered rows + Adam, one thread per element)
 #include "moc_common.h"
+#include <type_traits>
 #include "moc_p2p.h"
 
 int moc_check_batch(const moc_batch_t* B, const char* who);
@@ -1109,6 +1110,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     const int b = a.slide0, C = a.C, K = a.K, D = a.D;
     const int wg = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int DS = D / 16, d_lo = wg * DS;               // this workgroup's columns of W1
+    MOC_STAMP(40);
     const int esz = a.xdt == MOC_F32 ? 4 : 2;
     const int PMAX = C * K;
     // ---- LDS carve
@@ -1172,6 +1174,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
         k = pool_phase<8, 32, 2>(a, b, L, PS_CAP, wg == 0, pooled_out, topk_idx_out, topk_cnt_out, &base);
     }
     __syncthreads();
+    MOC_STAMP(41);
     // ---- pairs
     const int P = C * k;
     for (int p = t; p < 2 * P; p += 1024) mask[p] = 0u;
@@ -1202,6 +1205,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
             dz[p * 4 + i] = (a.use_bits >> i & 1u) ? gk * sc[i] * lv[i] * (1.f - lv[i]) : 0.f;
     }
     __syncthreads();
+    MOC_STAMP(42);
     // hidden rows of the pairs: ReLU mask (64 bits) and the four values this workgroup owns
     auto take_hidden = [&](int e, const float4& hv) {
         const int p = e >> 4, v = e & 15;
@@ -1215,6 +1219,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     for (int e = t + 5 * 1024; e < P * 16; e += 1024)           // more than 320 pairs
         take_hidden(e, *reinterpret_cast<const float4*>(a.H1 + (base + sidx_s[e >> 4]) * H + (e & 15) * 4));
     __syncthreads();                                       // masks complete
+    MOC_STAMP(43);
     // ---- W1 gradient: dW1[h][d] = sum_p dh[p][h] x[p][d], pairs in chunks of WD_PCH through `region`:
     // [PCH][DS] pieces of the pairs' rows as stored + [PCH][64] fp32 dh, then v_mfma_f32_16x16x4_f32 over p
     f32x4_t gacc = {0.f, 0.f, 0.f, 0.f};
@@ -1247,34 +1252,63 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
                 if (e < n * ppr) *reinterpret_cast<uint4*>(xraw + (size_t)e * 16) = xnext[q];
             }
             if (c0 + WD_PCH < P) request(c0 + WD_PCH);
-            for (int e = t; e < n4 * 64; e += 1024) {
-                const int pp = e >> 6, h = e & 63;
-                float v = 0.f;
-                if (pp < n && (mask[2 * (c0 + pp) + (h >> 5)] >> (h & 31) & 1u)) {
-                    const float4 z = *reinterpret_cast<const float4*>(dz + (c0 + pp) * 4);
-                    v = fmaf(z.w, W2s[3 * H + h], fmaf(z.z, W2s[2 * H + h], fmaf(z.y, W2s[H + h], z.x * W2s[h])));
-                }
-                dh_s[pp * 64 + h] = v;
-            }
-            __syncthreads();
-            if (has_tile) {
-                const int kq = lane >> 4, li = lane & 15;
-                for (int ks = 0; ks < n4; ks += 4) {
-                    const int pp = ks + kq;
-                    const float av = dh_s[pp * 64 + h0 + li];
-                    float bv = 0.f;
-                    if (pp < n) {
-                        const int cc = (d0 - d_lo) + li;
-                        if (a.xdt == MOC_F32) bv = reinterpret_cast<const float*>(xraw)[(size_t)pp * DS + cc];
-                        else if (a.xdt == MOC_F16) bv = moc_f16_to_f32(reinterpret_cast<const uint16_t*>(xraw)[(size_t)pp * DS + cc]);
-                        else bv = moc_bf16_to_f32(reinterpret_cast<const uint16_t*>(xraw)[(size_t)pp * DS + cc]);
+            if (c0 == 0) MOC_STAMP(50);
+            {   // dh of the chunk: thread = (hidden unit t & 63, pair t >> 6 + 16 m); its four W2 entries stay in registers
+                const int h = t & 63;
+                const float w0 = W2s[h], w1 = W2s[H + h], w2 = W2s[2 * H + h], w3 = W2s[3 * H + h];
+#pragma unroll
+                for (int m = 0; m < WD_PCH / 16; ++m) {                // (unrolled: the eight rounds' LDS reads overlap)
+                    const int pp = (t >> 6) + 16 * m;
+                    if (pp < n4) {
+                        float v = 0.f;
+                        if (pp < n && (mask[2 * (c0 + pp) + (h >> 5)] >> (h & 31) & 1u)) {
+                            const float4 z = *reinterpret_cast<const float4*>(dz + (c0 + pp) * 4);
+                            v = fmaf(z.w, w3, fmaf(z.z, w2, fmaf(z.y, w1, z.x * w0)));
+                        }
+                        dh_s[pp * 64 + h] = v;
                     }
-                    gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, gacc, 0, 0, 0);
                 }
             }
+            if (c0 == 0) MOC_STAMP(51);
+            __syncthreads();
+            if (c0 == 0) MOC_STAMP(52);
+            if (has_tile) {
+                const int kq = lane >> 4, li = lane & 15, cc = (d0 - d_lo) + li;
+                // eight k = 4 steps at a time: their sixteen LDS reads in flight together (one step at a time the read
+                // latency was exposed 32 times per chunk); storage type decided once, outside
+                auto product = [&](auto kind) {
+                    constexpr int XK = decltype(kind)::value;           // 0 fp32, 1 bf16, 2 fp16
+                    auto xval = [&](int pp) -> float {
+                        if constexpr (XK == 0) return reinterpret_cast<const float*>(xraw)[(size_t)pp * DS + cc];
+                        else if constexpr (XK == 2) return moc_f16_to_f32(reinterpret_cast<const uint16_t*>(xraw)[(size_t)pp * DS + cc]);
+                        else return moc_bf16_to_f32(reinterpret_cast<const uint16_t*>(xraw)[(size_t)pp * DS + cc]);
+                    };
+                    int ks = 0;
+                    for (; ks + 32 <= n4; ks += 32) {
+                        float av[8], bv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int pp = ks + 4 * u + kq;
+                            av[u] = dh_s[pp * 64 + h0 + li];
+                            bv[u] = pp < n ? xval(pp) : 0.f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], gacc, 0, 0, 0);
+                    }
+                    for (; ks < n4; ks += 4) {
+                        const int pp = ks + kq;
+                        gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(dh_s[pp * 64 + h0 + li], pp < n ? xval(pp) : 0.f, gacc, 0, 0, 0);
+                    }
+                };
+                if (a.xdt == MOC_F32) product(std::integral_constant<int, 0>{});
+                else if (a.xdt == MOC_F16) product(std::integral_constant<int, 2>{});
+                else product(std::integral_constant<int, 1>{});
+            }
+            if (c0 == 0) MOC_STAMP(53);
         }
     }
     __syncthreads();
+    MOC_STAMP(44);
     // ---- small gradients: 16 + 4 (+ 4) sums over the pairs, one per wave, pairs strided over the lanes
     {
         float part = 0.f;
@@ -1304,6 +1338,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
         }
         __syncthreads();
     }
+    MOC_STAMP(45);
     // ---- outputs
     const float gs = a.adam.grad_scale;
     float gv = 0.f;
@@ -1345,6 +1380,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
         else if (small >= H) { const int i = small - H; g.W2out[i] = pS; a.m_W2[i] = pSm; a.v_W2[i] = pSv; }
         else { a.b1[small] = pS; a.m_b1[small] = pSm; a.v_b1[small] = pSv; }
     }
+    MOC_STAMP(46);
 }
 
 // ------------------------------------------------------------------ W1 gradient (+ Adam)
