@@ -4,30 +4,41 @@ evaluation) on synthetic NSCLC 16-shot bags (32 slides x 15k x 512), BASELINE.js
 configs[1].
 
     python bench.py --gpus 1 --steps 1600 --warmup 160
+    python bench.py --gpus N --steps K --warmup W            # starts its own N ranks (one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one meta-step = one slide through mask -> scores -> 4 selectors ->
 union -> meta-learner -> top-K pooling -> CE -> backward -> Adam (main_moc.py:380-410),
 everything the reference's train() does per slide, bags already resident in HBM.
-At N > 1 a step is one synchronous data-parallel step (one slide per rank, RCCL
-all-reduce of the meta-gradient); value counts slides consumed by all ranks.
 
-Prints ONE JSON line on rank 0.  Extra keys: roofline (dominant kernel = the score
-pass, timed live with events on the launch stream), cpu_baseline (the oracle's
-train loop on this box's host cores, bounded sample), eval slides/sec.
+At N > 1 the task stays the SAME 16-shot task and, by default (`--train-mode seq`), the SAME optimisation: the
+exact-sequential mode (moc_amd.dist.train_seq, SURVEY.md section 8e mode 1) shards the bags and phase A over the GPUs,
+all-gathers the compact phase-A results and runs the reference's one-Adam-step-per-slide recurrence on every rank --
+bit-identical to one GPU, hence the reference's AUC; a step is still one slide and `value` counts slides per second.
+Minibatch data parallelism (`--train-mode dp`: one slide per rank per synchronous step, the meta-gradient summed over
+the ranks, one Adam step per N slides) is faster but changes the trajectory -- measured AUC deviations of 0.01-0.2
+from the sequential run at every N and learning-rate rule (profiles/round2_dp_auc_study.jsonl), outside the +-0.002
+bar -- so it is an opt-in extension; a default N > 1 run reports it under `minibatch_dp` (strong: the same slides
+sharded, `--scaling`; weak: every rank its own) from shorter runs of the same process.
+
+Prints ONE JSON line on rank 0.  Extra keys: steady_state (>= 50 whole epochs of the same model in the
+same run: what a training run of many epochs sees, whatever --steps was), roofline (dominant kernel =
+the score pass, timed live with events on the launch stream), cpu_baseline (the oracle's train loop on
+this box's host cores, bounded sample), eval slides/sec.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import types
 
 # dmabuf IPC (peer-mapped exchange buffers, RCCL): must be in the environment before the HIP runtime starts
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
-import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -66,13 +77,87 @@ def parse():
     ap.add_argument("--lognormal", action="store_true", help="log-normal bag sizes around --patches")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--no-steady", action="store_true", help="skip the steady_state block")
+    ap.add_argument("--steady-epochs", type=int, default=50)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--train-mode", default="seq", choices=["seq", "dp"],
+                    help="N > 1: seq = exact-sequential (one Adam step per slide, bit-identical to one GPU; default); "
+                         "dp = minibatch data parallelism (one step per N slides: changes the trajectory)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="--train-mode dp: strong = the same --slides slides sharded over the ranks (the BASELINE metric); "
+                         "weak = every rank its own --slides slides")
+    ap.add_argument("--no-dp-extra", action="store_true", help="N > 1, seq: skip the minibatch_dp extra block")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel trainer even at 1 GPU (rehearsal)")
     return ap.parse_args()
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks of this script (one per GPU) BEFORE this
+    process has made any GPU call, relay rank 0's JSON line and the first non-zero exit code.  (Never re-exec a
+    process that has touched the GPU; this parent never does.)"""
+    port = _free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MOC_BENCH_CHILD="1")
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    line, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()                                   # exactly the child this parent started
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
+def workload_name(a):
+    C = a.classes
+    if C == 2 and a.slides == 32 and a.dim == 512:
+        name = "NSCLC 2-way 16-shot"
+    elif C == 3 and a.slides == 48 and a.dim == 512:
+        name = "RCC 3-way 16-shot"
+    elif C == 30 and a.slides == 120 and a.dim == 512:
+        name = "EBRAINS-30 30-way 4-shot"
+    else:
+        name = f"synthetic {C}-way"
+    return (f"{name} train loop: {a.slides} slides/epoch x {'~' if a.lognormal else ''}{a.patches} patches x {a.dim}, "
+            f"topj {a.topj}, topk {a.topk}, row mask on")
+
+
+def measured_traffic(kname, avg_bytes):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (scripts/pmc_traffic.py) -- only when that
+    capture is of THIS kernel, THIS source and a launch of THIS size; otherwise None (never a number from another run)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        src = hashlib.sha256(open(os.path.join(ROOT, "moc_amd", "csrc", "moc_scores.hip"), "rb").read()).hexdigest()[:16]
+        if tj.get("kernel") != kname or tj.get("scores_src_sha16") != src:
+            return None
+        if abs(tj.get("algorithmic_bytes_per_launch", 0) - avg_bytes) > 0.01 * avg_bytes:
+            return None
+        return {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                "WRITE_SIZE, separate passes, same kernel source and launch size)", "captured_at": tj.get("git_head")}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)                      # does not return
+    import torch
     # stdout carries the ONE JSON line and nothing else: whatever libraries print there (librccl announces its
     # path on stdout when a communicator is created) goes to stderr instead
     sys.stdout.flush()
@@ -81,73 +166,59 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    one_device = os.environ.get("MOC_BENCH_ONE_DEVICE") == "1"     # rehearsal: all ranks on one card (not a measurement)
+    assert n_dev >= world or one_device, f"--gpus {world} but this node shows {n_dev} GPU(s)"
+    dev = torch.device("cuda", local_rank % n_dev if one_device else local_rank)
     torch.cuda.set_device(dev)
     cpus = granted_cpus()
     torch.set_num_threads(max(1, min(8, cpus // max(1, world))))   # the GPU leg's host side is serial
     import torch.distributed as dist
-    if world > 1 or a.force_dp:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dp = world > 1 or a.force_dp
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from moc_amd import engine, main_moc as M, synth
     from moc_amd import dist as mdist
 
     C, D, j, K = a.classes, a.dim, a.topj, a.topk
     store = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(a.dtype, torch.float32)
+    esz = 4 if a.dtype == "fp32" else 2
     W, We = synth.make_bank(1234, D, C)
     M.set_classifier_bank(W.to(dev), We.to(dev))
-    sizes = synth.bag_sizes(99 + rank, a.slides, a.patches, fixed=not a.lognormal)
-    # weak scaling: every rank owns its own 32-slide shard (different seeds)
-    bags = [synth.make_bag_device(1234 + 1000 * rank + i, n, D, We, C, i % C, dev, store) for i, n in enumerate(sizes)]
-    labels = [i % C for i in range(a.slides)]
-    res = M.ResidentBags(bags, labels, dev)
-    del bags
     args = types.SimpleNamespace(disable_tqdm=True, n_classes=C, topj=j, topk=K, discard_classifiers=[],
                                  pretrain="conch", ablation_study="none")
-    torch.manual_seed(0)
-    model = M.senet(D, 4).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    all_sizes = synth.bag_sizes(99, a.slides, a.patches, fixed=not a.lognormal)
 
-    engine.SCORE_EVENTS = []          # (start, stop, algorithmic bytes) per score-pass launch
+    def make_split(mode):
+        """This rank's resident train split.  seq: the contiguous block [rank*per, (rank+1)*per) of the ONE task's
+        slides (phase A shards, the recurrence does not); dp_strong: slide i of the ONE task lives on rank i mod world
+        (step t consumes slides [t*world, (t+1)*world)); dp_weak / single: a whole task of its own per rank."""
+        if mode == "seq":
+            per = (a.slides + world - 1) // world
+            ids = list(range(min(a.slides, rank * per), min(a.slides, (rank + 1) * per)))
+            bags = [synth.make_bag_device(1234 + i, all_sizes[i], D, We, C, i % C, dev, store) for i in ids]
+            return mdist.SeqShardedBags(bags, all_sizes, [i % C for i in range(a.slides)], dev, rank, world)
+        if mode == "dp_strong" and world > 1:
+            assert a.slides % world == 0, "--scaling strong: --slides must be a multiple of --gpus"
+            ids = list(range(rank, a.slides, world))
+            bags = [synth.make_bag_device(1234 + i, all_sizes[i], D, We, C, i % C, dev, store) for i in ids]
+            return M.ResidentBags(bags, [i % C for i in ids], dev)
+        sizes = all_sizes if rank == 0 else synth.bag_sizes(99 + rank, a.slides, a.patches, fixed=not a.lognormal)
+        bags = [synth.make_bag_device(1234 + 1000 * rank + i, n, D, We, C, i % C, dev, store) for i, n in enumerate(sizes)]
+        return M.ResidentBags(bags, [i % C for i in range(a.slides)], dev)
 
-    def run_steps(n_steps):
-        """n_steps meta-steps: whole epochs of a.slides, then a partial epoch."""
-        done = 0
-        while done < n_steps:
-            m = min(a.slides, n_steps - done)
-            res.repeat_num = m if m < a.slides else None
-            if world == 1 and not a.force_dp:
-                M.train(model, res, opt, dev, args)
-            else:
-                mdist.train_dp(model, res, opt, dev, args)
-            done += m
-        res.repeat_num = None
-
-    # work arrays for every pass length that will occur (whole epochs, and the partial epoch when --warmup or
-    # --steps is not a multiple of --slides) are allocated here, not inside the timed region; no step is run
-    bank0 = M._bank_for(res.X, dev)
-    for m in {a.slides, a.warmup % a.slides, a.steps % a.slides} - {0}:
-        res.repeat_num = m if m < a.slides else None
-        res.train_plan(bank0.C, bank0.Ce, j, K, [])
-    res.repeat_num = None
-
-    def prime():
-        """Runtime warm-up that is not training: a throw-away meta-learner goes through a few passes of every
-        length that will occur, so that code objects, allocator pools, the side stream and the pass-ahead
-        pipeline exist before the W warm-up steps of the model that is measured (whatever W and K are)."""
-        nonlocal model, opt
-        keep = (model, opt)
-        model = M.senet(D, 4).to(dev)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
-        for m in sorted({a.slides, a.warmup % a.slides, a.steps % a.slides} - {0}, reverse=True):
-            run_steps(3 * m if m == a.slides else m)
-        run_steps(a.slides)
-        model, opt = keep
+    def new_model():
+        torch.manual_seed(0)
+        m = M.senet(D, 4).to(dev)
+        return m, torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4)
 
     def fence():
         torch.cuda.synchronize()
@@ -155,7 +226,63 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def ranks_agree():
+    def max_over_ranks(dt):
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            if one_device:
+                t = t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    class Loop:
+        """The train loop over one resident split: passes of `per_pass` steps (an epoch), the last one of a run
+        possibly partial.  Every pass is told the length of the pass that follows it, so that its phase A -- issued a
+        pass ahead on the side stream, as in a run of many epochs -- is for the right visits even when --warmup or
+        --steps is not a whole number of epochs."""
+
+        def __init__(self, res, model, opt, mode):
+            self.res, self.model, self.opt, self.mode = res, model, opt, mode
+            self.per_pass = res.real_len()
+
+        def schedule(self, n_steps):
+            out, done = [], 0
+            while done < n_steps:
+                out.append(min(self.per_pass, n_steps - done))
+                done += out[-1]
+            return out
+
+        def run(self, lengths, then=None):
+            """Passes of the given lengths; `then` = length of the pass the caller runs next (None: nothing follows,
+            no phase A is issued ahead)."""
+            res = self.res
+            for i, m in enumerate(lengths):
+                nxt = lengths[i + 1] if i + 1 < len(lengths) else then
+                res.repeat_num = m if m < self.per_pass else None
+                res.next_pass_len = nxt if nxt is not None else 0      # 0: no pass follows
+                if self.mode == "seq":
+                    mdist.train_seq(self.model, res, self.opt, dev, args)
+                elif self.mode in ("dp_strong", "dp_weak"):
+                    mdist.train_dp(self.model, res, self.opt, dev, args)
+                else:
+                    M.train(self.model, res, self.opt, dev, args)
+            res.repeat_num = None
+            res.next_pass_len = None
+
+        def allocate(self, lengths):
+            """Work arrays for every pass length that will occur: allocated here, not inside a timed region."""
+            if self.mode == "seq":
+                bank0 = M._bank_for(self.res.local.X, dev)
+                for m in set(lengths):
+                    mdist._seq_plan(self.res, m, bank0, args)
+                return
+            bank0 = M._bank_for(self.res.X, dev)
+            for m in set(lengths):
+                self.res.repeat_num = m if m < self.per_pass else None
+                self.res.train_plan(bank0.C, bank0.Ce, j, K, [])
+            self.res.repeat_num = None
+
+    def ranks_agree(model):
         """Data-parallel sanity: no exchange time-out anywhere and bit-identical parameters on every rank."""
         if world == 1:
             return True
@@ -163,44 +290,95 @@ def main():
         h = flat.view(torch.int32).to(torch.int64)
         sig = torch.stack([h.sum(), (h * torch.arange(1, h.numel() + 1, device=dev)).sum(),
                            torch.tensor(mdist.exchange_error(), device=dev, dtype=torch.int64)])
+        if one_device:
+            sig = sig.cpu()
         lo, hi = sig.clone(), sig.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         return bool(torch.equal(lo, hi)) and int(hi[2].item()) == 0
 
-    prime()
-    run_steps(a.warmup)
-    fence()
-    exchange = getattr(mdist.train_dp, "exchange", None)
-    if world > 1 and not ranks_agree():
-        # the in-kernel exchange misbehaved on this node: fall back to the RCCL collective, from scratch
-        if rank == 0:
-            print(f"bench: ranks disagree after warm-up with exchange={exchange}; re-running with the collective",
-                  file=sys.stderr)
-        assert exchange == "p2p", "ranks disagree on the collective path"
-        os.environ["MOC_DP_EXCHANGE"] = "rccl"
-        torch.manual_seed(0)
-        model = M.senet(D, 4).to(dev)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
-        run_steps(a.warmup)
+    def measure(mode, n_steps, n_warm, steady_epochs):
+        """-> dict(value, dt, steady, loop, exchange, fallback) for one scaling mode.  The timed region is EXACTLY
+        n_steps steps between two fences, after n_warm untimed steps of the same model."""
+        res = make_split(mode)
+        model, opt = new_model()
+        loop = Loop(res, model, opt, mode)
+        units = world if mode in ("dp_strong", "dp_weak") else 1     # slides one step consumes, over the whole job
+        warm, timed = loop.schedule(n_warm), loop.schedule(n_steps)
+        steady = [loop.per_pass] * steady_epochs
+        loop.allocate(warm + timed + steady)
+        fallback = None
+
+        def prime():
+            """Runtime warm-up that is not training: a throw-away meta-learner goes through a few passes of every
+            length that will occur, so that code objects, allocator pools, the side stream and the pass-ahead pipeline
+            exist before the W warm-up steps of the model that is measured (whatever W and K are)."""
+            m2, o2 = M.senet(D, 4).to(dev), None
+            o2 = torch.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=1e-4)
+            tmp = Loop(res, m2, o2, mode)
+            seq = []
+            for m in sorted(set(warm + timed + steady), reverse=True):
+                seq += [m] * (3 if m == loop.per_pass else 1)
+            tmp.run(seq + [loop.per_pass], then=(warm + timed)[0])
+
+        prime()
+        loop.run(warm, then=timed[0])
         fence()
-        exchange = mdist.train_dp.exchange
-        assert ranks_agree(), "ranks disagree on the collective path"
-    engine.SCORE_EVENTS.clear()
-    t0 = time.perf_counter()
-    run_steps(a.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    units = a.steps * world                      # slides consumed by the whole job
-    value = units / dt
-    assert ranks_agree(), "data-parallel ranks ended the timed region with different parameters"
+        exchange = getattr(mdist.train_dp, "exchange", None) if mode.startswith("dp") else None
+        if world > 1 and not ranks_agree(model):
+            # the in-kernel exchange misbehaved on this node: fall back to the RCCL collective, from scratch
+            err = mdist.exchange_error()
+            if rank == 0:
+                print(f"bench: ranks disagree after warm-up with exchange={exchange} (error word {err}); "
+                      "re-running with the collective", file=sys.stderr)
+            assert exchange == "p2p", "ranks disagree on the collective path"
+            fallback = {"from": "p2p", "exchange_error": err}
+            mdist.drop_p2p()                      # collective: the errored exchange is closed and forgotten everywhere
+            os.environ["MOC_DP_EXCHANGE"] = "rccl"
+            model, opt = new_model()
+            loop = Loop(res, model, opt, mode)
+            loop.run(warm, then=timed[0])
+            fence()
+            exchange = mdist.train_dp.exchange
+            assert ranks_agree(model), "ranks disagree on the collective path"
+        if engine.SCORE_EVENTS is not None:
+            engine.SCORE_EVENTS.clear()
+        t0 = time.perf_counter()
+        loop.run(timed, then=(steady[0] if steady else None))
+        fence()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        ev = list(engine.SCORE_EVENTS) if engine.SCORE_EVENTS is not None else []
+        assert ranks_agree(model), "data-parallel ranks ended the timed region with different parameters"
+        out = {"value": n_steps * units / dt, "dt": dt, "loop": loop, "exchange": exchange, "fallback": fallback,
+               "events": ev, "steady": None, "res": res, "model": model}
+        if steady:
+            # the same model keeps training: whole epochs only, the pass-ahead pipeline in its periodic state
+            engine_events, engine.SCORE_EVENTS = engine.SCORE_EVENTS, None
+            fence()
+            t0 = time.perf_counter()
+            loop.run(steady, then=None)
+            fence()
+            sdt = max_over_ranks(time.perf_counter() - t0)
+            engine.SCORE_EVENTS = engine_events
+            n = steady_epochs * loop.per_pass
+            out["steady"] = {"value": round(n * units / sdt, 1), "unit": "meta-steps/s", "epochs": steady_epochs,
+                             "steps": n, "ms_per_step": round(sdt / n * 1e3, 5),
+                             "note": "whole epochs of the same model right after the timed region (same process, same "
+                                     "clocks): the rate a run of many epochs sees"}
+            assert ranks_agree(model), "data-parallel ranks ended the steady-state block with different parameters"
+        return out
+
+    engine.SCORE_EVENTS = []          # (start, stop, algorithmic bytes) per score-pass launch
+    if world == 1:
+        main_mode = "dp_weak" if a.force_dp else "single"
+    else:
+        main_mode = "seq" if a.train_mode == "seq" else "dp_" + a.scaling
+    r = measure(main_mode, a.steps, a.warmup, 0 if a.no_steady else a.steady_epochs)
+    value, dt, loop, exchange = r["value"], r["dt"], r["loop"], r["exchange"]
+    res, model = r["res"], r["model"]
 
     # ---- roofline of the dominant kernel (score pass), from live events on the launch stream
-    ev = engine.SCORE_EVENTS
+    ev = r["events"]
     ms = [s.elapsed_time(e) for s, e, _ in ev]
     by = [b for _, _, b in ev]
     engine.SCORE_EVENTS = None
@@ -210,7 +388,6 @@ def main():
         avg_bytes = sum(by) / len(by)
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
         # the kernel moc_scores launches for this shape (moc_scores.hip), as rocprofv3 names it
-        esz = 4 if a.dtype == "fp32" else 2
         nt = (C + 4 + 15) // 16
         half, f16 = ("true", "true" if a.dtype == "fp16" else "false") if esz == 2 else ("false", "false")
         if nt <= (3 if esz == 2 else 4):
@@ -223,59 +400,80 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
                 "launches": len(ms)}
+        tr = measured_traffic(kname, avg_bytes)
+        if tr:
+            roof["traffic"] = tr["hbm_bytes_per_launch"]
+            roof["traffic_source"] = tr["source"]
         # the same launch with nothing else on the GPU (in the loop it shares the memory system with the previous
         # pass's meta-steps on the main stream): the last train batch, as it stands, ten launches
-        last = (M.train.last if world == 1 and not a.force_dp else mdist.train_dp.last)[0]
+        last = (mdist.train_seq.last_local if main_mode == "seq" else
+                mdist.train_dp.last[0] if main_mode.startswith("dp") else M.train.last[0])
+        Xl = res.local.X if main_mode == "seq" else res.X
         torch.cuda.synchronize()
         iso = []
         for _ in range(10):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             check = engine.check
             e0.record()
-            check(engine.lib().moc_scores(engine.C.byref(last.c), engine.ptr(M._bank_for(res.X, dev).image), engine._stream()), "moc_scores")
+            check(engine.lib().moc_scores(engine.C.byref(last.c), engine.ptr(M._bank_for(Xl, dev).image), engine._stream()), "moc_scores")
             e1.record()
             torch.cuda.synchronize()
             iso.append(e0.elapsed_time(e1))
         iso_ms = sorted(iso)[len(iso) // 2]
         iso_bytes = last.kept_rows_host * D * esz
         roof["alone"] = {"achieved": round(iso_bytes / (iso_ms * 1e-3) / 1e9, 1),
-                         "frac": round(iso_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launch_us": round(iso_ms * 1e3, 2)}
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            try:
-                tj = json.load(open(tp))
-                if tj.get("dtype") == a.dtype and tj.get("slides") == a.slides and tj.get("patches") == a.patches:
-                    roof["traffic"] = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                pass
+                         "frac": round(iso_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launch_us": round(iso_ms * 1e3, 2),
+                         "algorithmic_bytes": int(iso_bytes)}
 
-    # ---- evaluation throughput (slides/sec), batched end to end
+    # ---- the modes that are not `value`, from shorter runs of this process, as extra keys (N > 1 only)
+    extras = {}
+    if world > 1 and not (main_mode == "seq" and a.no_dp_extra):
+        del res, loop
+        r["res"] = r["loop"] = None
+        todo = [m for m in ("dp_strong", "dp_weak") if m != main_mode and not (m == "dp_strong" and a.slides % world)]
+        for omode in todo:
+            per = a.slides if omode == "dp_weak" else a.slides // world
+            k2 = max(per, min(a.steps, 10 * per))
+            r2 = measure(omode, k2, min(a.warmup, per), 0)
+            extras[omode] = {"value": round(r2["value"], 1), "unit": "meta-steps/s (slides consumed by all ranks)",
+                             "sync_steps": k2, "ms_per_sync_step": round(r2["dt"] / k2 * 1e3, 5), "exchange": r2["exchange"]}
+            if r2["fallback"]:
+                extras[omode]["exchange_fallback"] = r2["fallback"]
+            res, model = r2["res"], r2["model"]
+            r2["loop"] = None
+
+    # ---- evaluation throughput (slides/sec), batched end to end; slides sharded over the ranks, no data-path collective
     eval_rate = None
     if not a.no_eval:
-        esz = synth.bag_sizes(7 + rank, a.eval_slides, a.patches, fixed=not a.lognormal)
-        ebags = [synth.make_bag_device(777 + 1000 * rank + i, n, D, We, C, i % C, dev, store) for i, n in enumerate(esz)]
-        eres = M.ResidentBags(ebags, [i % C for i in range(a.eval_slides)], dev)
+        n_eval = a.eval_slides
+        ids = list(range(rank, n_eval, world))
+        esizes = synth.bag_sizes(7, n_eval, a.patches, fixed=not a.lognormal)
+        ebags = [synth.make_bag_device(777 + i, esizes[i], D, We, C, i % C, dev, store) for i in ids]
+        eres = M.ResidentBags(ebags, [i % C for i in ids], dev)
         del ebags
+
+        def eval_once():
+            if world == 1:
+                return M.evaluation(model, eres, dev, args)
+            return mdist.evaluation_dp(model, eres, dev, args, [i % C for i in range(n_eval)], ids,
+                                       [list(range(q, n_eval, world)) for q in range(world)])
         for _ in range(3):                       # first pass allocates the plan; two more settle the clocks
-            M.evaluation(model, eres, dev, args)
+            eval_once()
         fence()
         reps = 20
         t0 = time.perf_counter()
         for _ in range(reps):
-            M.evaluation(model, eres, dev, args)
+            eval_once()
         fence()
-        edt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([edt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            edt = float(t.item())
-        eval_rate = reps * a.eval_slides * world / edt
+        edt = max_over_ranks(time.perf_counter() - t0)
+        eval_rate = reps * n_eval / edt
         del eres
 
     # ---- CPU baseline: the oracle's train loop on the host cores (rank 0, N=1 only)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         from oracle import moc_oracle as O
+        labels = res.labels
         cpu_bags = [res.X[res.starts[i]:res.starts[i + 1]].to(torch.float32).cpu() for i in range(a.slides)]
         torch.manual_seed(0)
         cm = O.Senet(D, 4)
@@ -302,26 +500,43 @@ def main():
                          f"(fp32 copies of the bag values, torch-CPU oracle, {threads} threads)"}
 
     if rank == 0:
+        if world == 1:
+            par = "single GPU, one Adam step per slide"
+        elif main_mode == "seq":
+            par = (f"seq{world}: exact-sequential -- bags and phase A (mask, scores, selectors, union) sharded over the {world} GPUs "
+                   f"in contiguous blocks of {(a.slides + world - 1) // world} slides, compact results all-gathered (RCCL) a pass "
+                   "ahead, every rank runs the one-Adam-step-per-slide recurrence: bit-identical to one GPU")
+        else:
+            how = ("inside the step kernel (peer-mapped xGMI buffers)" if exchange == "p2p" else "by one RCCL all-reduce")
+            par = (f"dp{world}: one slide per rank per synchronous step, 33,092-float meta-gradient summed over the ranks {how}; "
+                   + (f"the same {a.slides} slides sharded over the ranks ({a.slides // world} steps per epoch)"
+                      if main_mode == "dp_strong" else f"{a.slides} slides of its own per rank")
+                   + "; CHANGES the optimisation trajectory (one Adam step per N slides)")
         out = {
             "metric": "meta-steps/sec (train), slides/sec (eval) on 16-shot NSCLC synthetic bags",
             "value": round(value, 1), "unit": "meta-steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"NSCLC {C}-way 16-shot train loop: {a.slides} slides/epoch x "
-                                   f"{'~' if a.lognormal else ''}{a.patches} patches x {D}, topj {j}, topk {K}, row mask on",
-                       "bag_storage": a.dtype, "arithmetic": "fp32 accumulate (MFMA)",
-                       "parallelism": "single GPU, one Adam step per slide" if world == 1 else
-                                      f"dp{world}: one slide per rank per step, 33,092-float meta-gradient summed over the ranks " +
-                                      ("inside the step kernel (peer-mapped xGMI buffers)" if exchange == "p2p"
-                                       else "by one RCCL all-reduce")},
+            "scaling": "weak" if main_mode in ("single", "dp_weak") else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload_name(a), "bag_storage": a.dtype, "arithmetic": "fp32 accumulate (MFMA)",
+                       "parallelism": par},
+            "steady_state": r["steady"],
             "eval_slides_per_sec": None if eval_rate is None else round(eval_rate, 1),
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if extras:
+            out["minibatch_dp" if main_mode == "seq" else "other_modes"] = dict(
+                extras, note="synchronous minibatch data parallelism: one Adam step per N slides -- an opt-in extension "
+                             "(--train-mode dp), its AUC is NOT within +-0.002 of the sequential reference "
+                             "(profiles/round2_dp_auc_study.jsonl)")
+        if r["fallback"]:
+            out["exchange_fallback"] = r["fallback"]
+        if one_device:
+            out["rehearsal"] = "all ranks on ONE device (MOC_BENCH_ONE_DEVICE=1): not a scaling measurement"
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if world > 1 or a.force_dp:
+    if dp:
         mdist.shutdown()
         dist.destroy_process_group()
 

@@ -10,8 +10,14 @@
  *
  * Conventions
  *   - every pointer marked "device" is HIP device memory owned by the caller
- *     (PyTorch tensors in practice); the library never allocates, frees or keeps
- *     device memory and holds no state between calls;
+ *     (PyTorch tensors in practice); the compute entry points never allocate, free or
+ *     keep device memory and hold no state between calls.  The ONE exception is the
+ *     node-local exchange handle `moc_p2p_t` (moc_p2p_create ... moc_p2p_destroy, below):
+ *     it owns its fine-grained receive buffers (hipExtMallocWithFlags), one pinned host
+ *     error word, the peers' IPC mappings and a sequence counter -- allocation and state
+ *     are confined to that handle, created and destroyed explicitly by the caller, and
+ *     exist only in a multi-rank run ("no cross-call state except an
+ *     optional handle for persistent-kernel resources");
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
  *     every call returns without synchronising the host;
  *   - return value 0 = success; otherwise a MOC_E* code, with a message
@@ -33,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 9
+#define MOC_ABI_VERSION 10
 
 enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
 
@@ -172,6 +178,15 @@ int moc_gather_candidates(const moc_batch_t* B, void* selected_feat, moc_stream_
 
 /* all four above, in order */
 int moc_phase_a(const moc_batch_t* B, const void* bank, moc_stream_t stream);
+
+/* Phase A's result for slides [slide0, slide0+n) in a fixed-capacity, position-independent form -- what
+ * slide_process hands to the meta-learner (main_moc.py:367-375: selected_feat + the four candidate matrices),
+ * `cap` rows per slide: feat_out device [n][cap][D] in X's dtype, cand_out device [n][2C+2][cap] fp32; entries at
+ * and beyond n_sel[slide] are not written.  The exact-sequential multi-GPU mode (SURVEY.md section 8e mode 1)
+ * all-gathers these blocks so that every GPU runs the reference's one-Adam-step-per-slide recurrence
+ * (main_moc.py:380-410) over slides whose phase A ran elsewhere. */
+int moc_pack_selected(const moc_batch_t* B, int slide0, int n, int cap, void* feat_out, float* cand_out,
+                      moc_stream_t stream);
 
 /* ---- phase B: meta-learner, pooling, loss, update ------------------------- */
 

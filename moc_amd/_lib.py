@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 MOC_F32, MOC_BF16, MOC_F16 = 0, 1, 2
 SEL_BITS = {"topk": 1, "delta_softmax": 2, "delta_diff": 4, "bottomk": 8}
@@ -63,6 +63,7 @@ SIGNATURES = {
     "moc_select": (C.c_int, [_BP, _p]),
     "moc_gather_candidates": (C.c_int, [_BP, _p, _p]),
     "moc_phase_a": (C.c_int, [_BP, _p, _p]),
+    "moc_pack_selected": (C.c_int, [_BP, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
     "moc_meta_forward": (C.c_int, [_BP, _MP, _WP, C.c_int, C.c_int, C.c_uint32, _p]),
     "moc_mix_fixed": (C.c_int, [_BP, _WP, C.c_int, C.c_int, C.c_int, _p]),
     "moc_pool_loss": (C.c_int, [_BP, _WP, _p, C.c_int, C.c_int, _p]),

@@ -57,7 +57,7 @@ extern "C" int64_t moc_host_draw_masks(uint8_t* rng_state, int64_t state_bytes, 
     const int32_t seeded = *reinterpret_cast<int32_t*>(rng_state + 12);
     uint64_t* next = reinterpret_cast<uint64_t*>(rng_state + 16);
     uint64_t* st64 = reinterpret_cast<uint64_t*>(rng_state + 24);
-    if (!seeded || *left < 0 || *left > MT_N || *next > (uint64_t)MT_N) {
+    if (!seeded || *left < 1 || *left > MT_N || *next > (uint64_t)MT_N) {
         moc_set_error("moc_host_draw_masks: unexpected generator state (left=%d next=%llu seeded=%d)", *left,
                       (unsigned long long)*next, seeded);
         return -1;

@@ -1864,7 +1864,12 @@ extern "C" int moc_train_steps_p2p(const moc_batch_t* B, const moc_meta_t* M, co
     if (int rc = check_meta(B, M, ws, "moc_train_steps_p2p", true, false)) return rc;
     MOC_REQUIRE(labels && slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_train_steps_p2p: bad labels/slide range");
     MOC_REQUIRE(comm, "moc_train_steps_p2p: null communicator");
-    MOC_REQUIRE(fused_step_mode(B, ws) != 0, "moc_train_steps_p2p: shape outside the one-launch steps (K <= 16, C <= 64, "
+    // Which step kernel runs is decided from the run's constants alone (as moc_p2p_step_supported does), never from
+    // this rank's bag sizes: the narrow and the wide kernel assign W1 elements to workgroups differently, and the
+    // per-workgroup arrival flags of the exchange only mean something when every rank runs the same one.
+    moc_batch_t Bu = *B;
+    Bu.max_rows = 0x7fffffff;
+    MOC_REQUIRE(fused_step_mode(&Bu, ws) != 0, "moc_train_steps_p2p: shape outside the one-launch steps (K <= 16, C <= 64, "
                 "D in {512, 1024} beyond C = 16); use moc_train_steps_dp");
     hipStream_t s = (hipStream_t)stream;
     if (int rc = launch_w1_image(B, M, s)) return rc;
@@ -1880,7 +1885,7 @@ extern "C" int moc_train_steps_p2p(const moc_batch_t* B, const moc_meta_t* M, co
         const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f / (float)x.world);
         Mt.W2 = cur;
         if (int rc = launch_forward(B, &Mt, ws, b, 1, use_bits, s)) return rc;
-        if (int rc = launch_fused_step(B, &Mt, ws, labels, b, use_bits, k, nxt, s, 1, &x)) return rc;
+        if (int rc = launch_fused_step(&Bu, &Mt, ws, labels, b, use_bits, k, nxt, s, 1, &x)) return rc;
         float* tmp = cur; cur = nxt; nxt = tmp;
     }
     if (cur != M->W2) {

@@ -257,6 +257,39 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(CompactArgs a) {
     }
 }
 
+// ---- compact hand-over of phase A's result (exact-sequential multi-GPU, SURVEY.md section 8e mode 1) ----------
+// grid (ceil(cap/16), n): slide slide0+y's selected rows -> feat_out[y][cap][D] (16 B per thread per step) and its
+// candidate scores -> cand_out[y][2C+2][cap]; entries at and beyond n_sel are left as they are.
+struct PackArgs {
+    const unsigned char* X;
+    const int64_t* row_off;
+    const int64_t* sel_row;
+    const int32_t* n_sel;
+    const float* cand;
+    unsigned char* feat_out;
+    float* cand_out;
+    int64_t stride;
+    int row_bytes, C, cap, slide0;
+};
+
+__global__ __launch_bounds__(256) void pack_selected_kernel(PackArgs a) {
+    const int y = blockIdx.y, b = a.slide0 + y;
+    const int64_t base = a.row_off[b];
+    const int S = min(a.n_sel[b], a.cap);
+    const int vec_per_row = a.row_bytes / 16;
+    const int s = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (s < S) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.X + a.sel_row[base + s] * (int64_t)a.row_bytes);
+        uint4* dst = reinterpret_cast<uint4*>(a.feat_out + ((int64_t)y * a.cap + s) * a.row_bytes);
+        for (int v = threadIdx.x & 15; v < vec_per_row; v += 16) dst[v] = src[v];
+    }
+    const int nk = 2 * a.C + 2;
+    for (int e = threadIdx.x; e < nk * 16; e += 256) {
+        const int k = e >> 4, t = blockIdx.x * 16 + (e & 15);
+        if (t < S) a.cand_out[((int64_t)y * nk + k) * a.cap + t] = a.cand[(int64_t)k * a.stride + base + t];
+    }
+}
+
 // ---- generic top-K mean ------------------------------------------------------
 constexpr int TK_CAND = 1024;      // candidate list of topk_mean_kernel's K <= 16 path
 
@@ -459,6 +492,21 @@ extern "C" int moc_gather_candidates(const moc_batch_t* B, void* selected_feat, 
         gather_rows_kernel<<<dim3(gx, B->n_slides), 256, 0, s>>>(a);
         MOC_CHECK_LAUNCH("moc_gather_candidates(gather)");
     }
+    return MOC_OK;
+}
+
+extern "C" int moc_pack_selected(const moc_batch_t* B, int slide0, int n, int cap, void* feat_out, float* cand_out,
+                                 moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_pack_selected")) return rc;
+    MOC_REQUIRE(B->sel_row && B->n_sel && B->cand, "moc_pack_selected: batch has no phase-A outputs");
+    MOC_REQUIRE(slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_pack_selected: bad slide range");
+    MOC_REQUIRE(cap >= 1 && feat_out && cand_out, "moc_pack_selected: bad cap/outputs");
+    PackArgs a;
+    a.X = (const unsigned char*)B->X; a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel; a.cand = B->cand;
+    a.feat_out = (unsigned char*)feat_out; a.cand_out = cand_out; a.stride = B->total_rows;
+    a.row_bytes = B->D * moc_elem_size(B->dtype); a.C = B->C; a.cap = cap; a.slide0 = slide0;
+    pack_selected_kernel<<<dim3(moc_cdiv(cap, 16), n), 256, 0, (hipStream_t)stream>>>(a);
+    MOC_CHECK_LAUNCH("moc_pack_selected");
     return MOC_OK;
 }
 

@@ -152,8 +152,9 @@ class Generic_MIL_Dataset:
                 self.get_split_from_df(all_splits, "test"))
 
 
-def to_resident(split: Generic_Split, device, dtype=None):
-    """Read every slide of `split` once and keep the split packed in HBM."""
+def to_resident(split: Generic_Split, device, dtype=None, loader_seed_draw=False):
+    """Read every slide of `split` once and keep the split packed in HBM.  `loader_seed_draw`: every pass makes the
+    base-seed draw the reference's DataLoader makes (main_moc.ResidentBags)."""
     from .main_moc import ResidentBags
     bags, labels, paths = [], [], []
     n = split.real_len()
@@ -162,7 +163,8 @@ def to_resident(split: Generic_Split, device, dtype=None):
         bags.append(feats.to(torch.float32))
         labels.append(int(split.slide_data["label"][i]))
         paths.append(path)
-    return ResidentBags(bags, labels, device, dtype=dtype, repeat_num=split.repeat_num, paths=paths)
+    return ResidentBags(bags, labels, device, dtype=dtype, repeat_num=split.repeat_num, paths=paths,
+                        loader_seed_draw=loader_seed_draw)
 
 
 def write_bag(data_dir: str, slide_id: str, features: torch.Tensor, coords=None, fmt="pt"):

@@ -255,6 +255,19 @@ def exchange_error() -> int:
     return 0
 
 
+def drop_p2p():
+    """Collective: close every peer-to-peer exchange and forget it (and its sticky error word), e.g. before a
+    re-run on the collective path after a time-out.  Nobody unmaps while a peer may still push: drain, barrier, close."""
+    if not _p2p:
+        return
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    for x in _p2p.values():
+        x.close()
+    _p2p.clear()
+
+
 def shutdown():
     for d in _direct.values():
         d.close()
@@ -312,6 +325,7 @@ def train_dp(model, loader, optimizer, device, args, group=None):
     model.train()
     use = engine.train_use_bits(args.discard_classifiers)
     if isinstance(loader, M.ResidentBags):
+        M._loader_seed_draw(loader)
         batch, lab, bank = M._resident_pass_setup(loader, device, args)
         sizes = batch.sizes
     else:
@@ -352,6 +366,234 @@ def train_dp(model, loader, optimizer, device, args, group=None):
     if resident:
         M.resident_pass_done(loader, device, args)
     train_dp.last = (batch, lab, fg)
+
+
+# --------------------------------------------------------------------------- exact-sequential multi-GPU (section 8e mode 1)
+class SeqShardedBags:
+    """A train split whose slides live on G GPUs -- rank r holds the contiguous block [r*per, (r+1)*per) of the
+    loader order -- for train_seq.  Every rank knows every slide's size and label (the mask stream and the labels
+    are global); only the bag rows are sharded.  Offers what main_moc's loops ask of a loader's dataset
+    (real_len(), repeat_num, len())."""
+
+    def __init__(self, my_bags, all_sizes, all_labels, device, rank: int, world: int, dtype=None):
+        from . import main_moc as M
+        self.all_sizes = [int(v) for v in all_sizes]
+        self.all_labels = [int(v) for v in all_labels]
+        n = len(self.all_sizes)
+        assert len(self.all_labels) == n and n >= 1
+        self.rank, self.world = int(rank), int(world)
+        self.per = (n + world - 1) // world
+        self.lo, self.hi = min(n, rank * self.per), min(n, (rank + 1) * self.per)
+        assert len(my_bags) == self.hi - self.lo, f"rank {rank} holds slides [{self.lo}, {self.hi}) of the loader order"
+        assert [int(b.size(0)) for b in my_bags] == self.all_sizes[self.lo:self.hi]
+        self.local = M.ResidentBags(my_bags, self.all_labels[self.lo:self.hi], device, dtype=dtype) if my_bags else None
+        self.device = torch.device(device)
+        self.repeat_num = None
+        self.next_pass_len = None
+        self.dataset = self
+        self._plans = {}
+
+    def real_len(self):
+        return len(self.all_sizes)
+
+    def __len__(self):
+        return self.repeat_num if self.repeat_num else len(self.all_sizes)
+
+
+def _seq_plan(sh: SeqShardedBags, m: int, bank, args):
+    from . import engine
+    from .engine import CompactBatch, SlideBatch
+    key = (m, bank.C, bank.Ce, args.topj, args.topk, tuple(sorted(args.discard_classifiers or ())))
+    plan = sh._plans.get(key)
+    if plan is not None:
+        return plan
+    assert m <= sh.real_len(), "train_seq: repeat_num beyond the split's slides is not supported"
+    dev, per, world = sh.device, sh.per, sh.world
+    n_loc = max(0, min(m, sh.hi) - sh.lo)                       # this rank's slides among the pass's first m visits
+    cap = min(args.topj * (2 * bank.C + 2), max(sh.all_sizes))  # a slide selects at most this many rows
+    starts = [0]
+    for v in sh.all_sizes:
+        starts.append(starts[-1] + v)
+    X = sh.local.X if sh.local is not None else None
+    dtype, D = bank.dtype, bank.D
+    sets = []
+    for _ in range(2):
+        local = None
+        if n_loc:
+            sizes = sh.local.sizes[:n_loc]
+            local = SlideBatch(X, sizes, bank.C, bank.Ce, args.topj, args.topk, args.discard_classifiers,
+                               mask=torch.ones(sum(sizes), dtype=torch.uint8), x_starts=sh.local.starts[:n_loc])
+        sets.append({
+            "local": local,
+            "send_feat": torch.zeros((per * cap, D), dtype=dtype, device=dev),
+            "send_cand": torch.zeros((per, 2 * bank.C + 2, cap), dtype=torch.float32, device=dev),
+            "send_nsel": torch.zeros(per, dtype=torch.int32, device=dev),
+            "compact": CompactBatch(per * world, cap, D, dtype, bank.C, bank.Ce, args.topj, args.topk, dev),
+            "stage": torch.empty(max(1, starts[min(m, sh.hi)] - starts[sh.lo]) if n_loc else 1, dtype=torch.uint8).pin_memory(),
+            "stage_free": None, "steps_done": None,
+        })
+    side = torch.cuda.Stream(device=dev)
+    for st in sets:
+        ts = [st["send_feat"], st["send_cand"], st["send_nsel"], st["compact"].X, st["compact"].cand,
+              st["compact"].cand_blocks, st["compact"].n_sel]
+        if st["local"] is not None:
+            b = st["local"]
+            ts += [t for t in (b.kept, b.n_kept, b.stats, b.sel_flag, b.sel_idx, b.sel_row, b.n_sel, b.cand, b.row_off, b.x_off) if t is not None]
+            X.record_stream(side)
+        for t in ts:
+            t.record_stream(side)
+    plan = sh._plans[key] = {
+        "sets": sets, "turn": 0, "ahead": None, "side": side, "m": m, "n_loc": n_loc, "cap": cap,
+        "row_lo": starts[sh.lo], "row_hi": starts[min(m, sh.hi)] if n_loc else starts[sh.lo], "rows_total": starts[m],
+        "labels": torch.tensor(sh.all_labels[:m] + [0] * (per * world - m), dtype=torch.int64).to(dev),
+        "all_masks": torch.empty(starts[m], dtype=torch.uint8),
+    }
+    return plan
+
+
+def _all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None):
+    """out = concatenation over the ranks of `inp` (equal shapes), on the current stream: ONE RCCL all-gather
+    ("nccl" backend); with gloo (the one-device tests) the list form over views of `out`."""
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, inp, group=group)
+        return
+    world = dist.get_world_size(group)
+    parts = out.view(world, *inp.shape)
+    dist.all_gather([parts[q] for q in range(world)], inp, group=group)
+
+
+def _seq_issue(sh, plan, turn, bank, rng_before, group, host_wait=None):
+    """Masks of the whole pass from generator state `rng_before` (every rank draws the same stream and keeps its own
+    rows), phase A of this rank's slides, their compact result into the send buffers, three all-gathers: afterwards
+    set `turn`'s CompactBatch holds the pass's phase-A result for ALL slides, in loader order.  On the CURRENT stream.
+    -> generator state after the draws (None: torch drew for us)."""
+    from . import engine
+    st = plan["sets"][turn]
+    if st["stage_free"] is not None:
+        st["stage_free"].synchronize()
+    _, _, rng_after = engine.draw_row_masks_from(rng_before, plan["rows_total"], plan["all_masks"])
+    if host_wait is not None:
+        host_wait.synchronize()
+    n_loc, cap = plan["n_loc"], plan["cap"]
+    if n_loc:
+        mine = plan["all_masks"][plan["row_lo"]:plan["row_hi"]]
+        st["stage"].copy_(mine)
+        b = st["local"]
+        b.use_host_mask(st["stage"], int(mine.sum()))
+        b.phase_a(bank)
+        engine.pack_selected(b, 0, n_loc, cap, st["send_feat"], st["send_cand"])
+        st["send_nsel"][:n_loc].copy_(b.n_sel)
+    cb = st["compact"]
+    if sh.world > 1:
+        _all_gather_into(cb.X, st["send_feat"], group)
+        _all_gather_into(cb.cand_blocks, st["send_cand"], group)
+        _all_gather_into(cb.n_sel, st["send_nsel"], group)
+    else:
+        cb.X.copy_(st["send_feat"])
+        cb.cand_blocks.copy_(st["send_cand"])
+        cb.n_sel.copy_(st["send_nsel"])
+    cb.blocks_to_columns()
+    ev = torch.cuda.Event()
+    ev.record()
+    st["stage_free"] = ev
+    return rng_after
+
+
+def train_seq(model, shard: SeqShardedBags, optimizer, device, args, group=None):
+    """Exact-sequential multi-GPU training pass (SURVEY.md section 8e mode 1): the reference's recurrence -- one Adam
+    step per slide, in loader order (main_moc.py:380-410) -- with phase A (everything in slide_process, which has no
+    trainable parameter) sharded over the GPUs that hold the bags.  Each rank runs phase A on its block of slides,
+    the compact results (selected rows, candidate scores, counts: moc_pack_selected) are all-gathered, and EVERY rank
+    then runs the same meta-steps over all slides, so all ranks hold bit-identical parameters -- the ones a single
+    GPU computes -- with no parameter broadcast.  Phase A + gather of the next pass are issued a pass ahead on a side
+    stream, as in main_moc.train.  Unlike train_dp this does not change the optimisation trajectory."""
+    from . import engine, main_moc as M
+    if not model.training:
+        model.train()
+    use = engine.train_use_bits(args.discard_classifiers)
+    X_like = shard.local.X if shard.local is not None else None
+    assert X_like is not None, "train_seq: every rank must hold at least one slide"
+    bank = M._bank_for(X_like, device)
+    assert bank.C == args.n_classes
+    m = len(shard)
+    plan = _seq_plan(shard, m, bank, args)
+    now = torch.get_rng_state()
+    ahead, plan["ahead"] = plan["ahead"], None
+    if ahead is not None and ahead["bank"] is bank and ahead["after"] is not None and torch.equal(ahead["before"], now):
+        torch.set_rng_state(ahead["after"])
+        torch.cuda.current_stream().wait_event(ahead["done"])
+        plan["turn"] = ahead["turn"]
+    else:
+        if ahead is not None:
+            ahead["done"].synchronize()
+        plan["turn"] = 1 - plan["turn"]
+        after = _seq_issue(shard, plan, plan["turn"], bank, now, group)
+        if after is not None:
+            torch.set_rng_state(after)
+    cb = plan["sets"][plan["turn"]]["compact"]
+    meta = engine.MetaState(model, optimizer)
+    engine.train_steps(cb, meta, plan["labels"], 0, m, use)
+    train_seq.last = (cb, plan["labels"])
+    train_seq.last_local = plan["sets"][plan["turn"]]["local"]
+    # ---- the next pass's phase A + gather, a pass ahead on the side stream (main_moc.resident_pass_done)
+    mark = torch.cuda.Event()
+    mark.record(torch.cuda.current_stream())
+    plan["sets"][plan["turn"]]["steps_done"] = mark
+    hint = shard.next_pass_len
+    if not M.PREFETCH_PHASE_A or hint == 0:
+        return
+    nplan = plan
+    if hint is not None and hint != m:
+        nplan = _seq_plan(shard, hint, bank, args)
+        if nplan["ahead"] is not None:
+            nplan["ahead"]["done"].synchronize()
+            nplan["ahead"] = None
+    other = 1 - nplan["turn"]
+    before = torch.get_rng_state()
+    with torch.cuda.stream(nplan["side"]):
+        after = _seq_issue(shard, nplan, other, bank, before, group, host_wait=nplan["sets"][other]["steps_done"])
+        done = torch.cuda.Event()
+        done.record(nplan["side"])
+    if after is None:
+        torch.set_rng_state(before)
+    nplan["ahead"] = {"turn": other, "before": before, "after": after, "done": done, "bank": bank}
+
+
+def train_minibatch(model, loader, optimizer, device, args, G: int):
+    """ONE process, one GPU: the optimisation trajectory of train_dp at world size G -- synchronous minibatches of G
+    consecutive slides (step t = slides [tG, (t+1)G) of the loader order, which is how a G-rank run shards them),
+    mean gradient, one Adam step per minibatch -- by gradient accumulation.  It exists to answer, without G GPUs,
+    whether minibatch data parallelism keeps the reference's AUC (SURVEY.md section 8e mode 2: "must be validated");
+    masks come from this process's generator in loader order (a G-rank run draws them per rank)."""
+    from . import engine, main_moc as M
+    assert G >= 1
+    model.train()
+    use = engine.train_use_bits(args.discard_classifiers)
+    X, sizes, x_starts, labels = M._collect(loader, device, args)
+    mask_all, _ = engine.draw_row_masks(sum(sizes))
+    masks, o = [], 0
+    for n in sizes:
+        masks.append(mask_all[o:o + n])
+        o += n
+    bank = M._bank_for(X, device)
+    batch = M._sub_batch(X, sizes, x_starts, list(range(len(sizes))), bank.C, bank.Ce, args.topj, args.topk,
+                         args.discard_classifiers, masks)
+    lab = torch.tensor(labels, dtype=torch.int64).to(device, non_blocking=True)
+    meta = engine.MetaState(model, optimizer, need_grads=True)
+    fg = FlatGrads(meta.params, device)
+    for name, v in zip(("g_W1", "g_b1", "g_W2", "g_b2"), fg.views):
+        setattr(meta.c, name, v.data_ptr())
+    acc = torch.zeros_like(fg.flat)
+    batch.phase_a(bank)
+    for t0 in range(0, len(sizes), G):
+        group = range(t0, min(t0 + G, len(sizes)))
+        acc.zero_()
+        for b in group:                                   # rank order: the same summation order as the exchange
+            engine.train_grad(batch, meta, lab, b, use)
+            acc += fg.flat
+        fg.flat.copy_(acc)
+        engine.adam_step(meta, grad_scale=1.0 / len(group))
+    train_minibatch.last = (batch, lab, fg)
 
 
 def evaluation_dp(model, loader, device, args, all_labels, my_ids, index_lists, group=None):

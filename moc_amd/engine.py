@@ -185,6 +185,46 @@ class SlideBatch:
         return self._ws
 
 
+class CompactBatch(SlideBatch):
+    """Phase A's RESULT for n slides, `cap` slots each, with no bag behind it: the selected rows themselves
+    (`Xc` [n*cap, D]), their candidate scores (`cand` [2C+2, n*cap]) and `n_sel` [n] -- what moc_pack_selected
+    writes and the exact-sequential multi-GPU mode all-gathers (dist.train_seq).  The phase-B entry points take it
+    like any batch: slot b*cap+i is row b*cap+i of Xc (sel_row is the identity)."""
+
+    def __init__(self, n_slides: int, cap: int, D: int, dtype: torch.dtype, C_: int, Ce: int, topj: int, topk: int, device):
+        T = n_slides * cap
+        self.device, self.n_slides, self.total, self.D = device, int(n_slides), T, int(D)
+        self.C, self.Ce, self.topj, self.topk, self.cap = int(C_), int(Ce), int(topj), int(topk), int(cap)
+        self.sizes = [cap] * n_slides
+        self.X = torch.zeros((T, D), dtype=dtype, device=device)
+        self.cand_blocks = torch.zeros((n_slides, 2 * self.C + 2, cap), dtype=torch.float32, device=device)
+        self.cand = torch.zeros((2 * self.C + 2, T), dtype=torch.float32, device=device)
+        self.n_sel = torch.zeros(n_slides, dtype=torch.int32, device=device)
+        self.sel_row = torch.arange(T, dtype=torch.int64, device=device)
+        off = [b * cap for b in range(n_slides + 1)]
+        self.row_off_host = off
+        self._row_off_c = (C.c_int64 * len(off))(*off)
+        self.row_off = torch.tensor(off, dtype=torch.int64).to(device)
+        self.discard_bits, self.mask, self.kept_rows_host = 0, None, T
+        self.c = MocBatch(
+            X=ptr(self.X), dtype=_dtype_code(dtype), D=self.D, total_rows=T, n_slides=self.n_slides, max_rows=cap,
+            row_off=ptr(self.row_off), row_off_host=C.cast(self._row_off_c, C.c_void_p), x_off=None, mask=None,
+            C=self.C, Ce=self.Ce, topj=self.topj, topk=self.topk, discard_bits=0, reserved=0, kept=None, n_kept=None,
+            stats=None, sel_flag=None, sel_idx=None, sel_row=ptr(self.sel_row), n_sel=ptr(self.n_sel), cand=ptr(self.cand))
+        self._ws = None
+
+    def blocks_to_columns(self):
+        """cand_blocks [n][2C+2][cap] (as gathered) -> cand [2C+2][n*cap] (as phase B reads it)."""
+        self.cand.view(2 * self.C + 2, self.n_slides, self.cap).copy_(self.cand_blocks.permute(1, 0, 2))
+
+
+def pack_selected(batch: SlideBatch, slide0: int, n: int, cap: int, feat_out: torch.Tensor, cand_out: torch.Tensor):
+    """moc_pack_selected: slides [slide0, slide0+n) of `batch` (phase A done) -> feat_out [n, cap, D], cand_out [n, 2C+2, cap]."""
+    assert feat_out.is_contiguous() and cand_out.is_contiguous() and feat_out.dtype == batch.X.dtype
+    assert feat_out.numel() >= n * cap * batch.D and cand_out.numel() >= n * (2 * batch.C + 2) * cap
+    check(lib().moc_pack_selected(C.byref(batch.c), slide0, n, cap, ptr(feat_out), ptr(cand_out), _stream()), "moc_pack_selected")
+
+
 class MetaState:
     """Views of a senet's parameters and its torch.optim.Adam state as the C ABI
     wants them.  The tensors are the optimizer's own (updated in place), so

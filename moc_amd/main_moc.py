@@ -17,8 +17,16 @@ How the loops map onto the GPU
   * evaluation / zs_evaluation have no sequential dependence at all and are
     batched end to end; only the [n_slides, C] pooled logits come back to the
     host, where sklearn computes the AUC as in the reference.
-  * the row mask is drawn with torch.rand on the CPU default generator, one call
-    per slide in loader order, exactly the stream main_moc.py:330 consumes.
+  * the row mask is drawn on the CPU default generator, one `torch.rand(N) > 0.5`
+    per slide in loader order (main_moc.py:330).  Given the same generator state at
+    the first slide, the bits are the reference's.  What differs is what ELSE draws
+    from that generator: the reference iterates a DataLoader(num_workers=1), and every
+    DataLoader.__iter__ -- train and each evaluation pass -- first draws a 64-bit base
+    seed from the same generator.  A torch DataLoader handed to train()/evaluation()
+    here makes that draw too (same stream as the reference); a ResidentBags split does
+    not unless built with `loader_seed_draw=True` (then every pass over it consumes the
+    draw, and phase A is no longer issued a pass ahead: the generator state the next
+    train() will find is not known in advance).
 """
 from __future__ import annotations
 
@@ -108,8 +116,13 @@ class ResidentBags:
     items; .dataset.real_len(), .dataset.repeat_num, len()).  train/evaluation
     recognise it and skip the per-epoch re-read + host->device copy."""
 
-    def __init__(self, bags, labels, device, dtype=None, repeat_num=None, paths=None):
+    def __init__(self, bags, labels, device, dtype=None, repeat_num=None, paths=None, loader_seed_draw=False):
         dtype = dtype or bags[0].dtype
+        # True: every pass over this split first draws the 64-bit base seed a DataLoader.__iter__ would draw from the
+        # CPU default generator (the reference's loaders do, train and evaluation alike), so a seeded run sees the
+        # reference's mask stream exactly; phase A is then not issued a pass ahead (module docstring)
+        self.loader_seed_draw = bool(loader_seed_draw)
+        self.next_pass_len = None          # see resident_pass_done
         self.X, self.sizes = _pack(bags, device, dtype)
         self.labels = [int(v) for v in labels]
         self.repeat_num = repeat_num
@@ -310,30 +323,48 @@ def _resident_pass_setup(res, device, args):
 
 
 def resident_pass_done(res, device, args):
-    """Call after the pass's meta-steps are issued: starts phase A of the NEXT pass on the side stream."""
-    if not PREFETCH_PHASE_A:
+    """Call after the pass's meta-steps are issued: starts phase A of the NEXT pass on the side stream.
+
+    The next pass is taken to visit what this one visited (the reference's epoch loop, main_moc.py:606-628).  A
+    caller that knows better says so in `res.next_pass_len`: a number of visits (bench.py's partial passes), or 0
+    for "no pass follows" (nothing is issued ahead)."""
+    if not PREFETCH_PHASE_A or res.loader_seed_draw:
         return
     bank = _bank_for(res.X, device)
     plan = res.train_plan(bank.C, bank.Ce, args.topj, args.topk, args.discard_classifiers)
-    turn, other = plan["turn"], 1 - plan["turn"]
-    main, side = torch.cuda.current_stream(), plan["side"]
+    main = torch.cuda.current_stream()
     # a set of arrays is free again when the meta-steps that read it have run: mark this pass's end on `main`;
     # the other set was last read by the PREVIOUS pass's meta-steps (their mark was left one call ago), so the
     # side stream waits for that one only and phase A of the next pass overlaps THIS pass's meta-steps
     mark = torch.cuda.Event()
     mark.record(main)
-    plan.setdefault("steps_done", [None, None])[turn] = mark
+    plan.setdefault("steps_done", [None, None])[plan["turn"]] = mark
+    hint = getattr(res, "next_pass_len", None)
+    if hint == 0:
+        return
+    nplan = plan
+    if hint is not None and hint != len(res):
+        keep, res.repeat_num = res.repeat_num, (hint if hint != res.real_len() else None)
+        try:
+            nplan = res.train_plan(bank.C, bank.Ce, args.topj, args.topk, args.discard_classifiers)
+        finally:
+            res.repeat_num = keep
+        if nplan.get("ahead") is not None:                # (an unadopted speculation of that plan still owns a set)
+            nplan["ahead"]["done"].synchronize()
+            nplan["ahead"] = None
+    nplan["bank"] = bank
+    other, side = 1 - nplan["turn"], nplan["side"]
     before = torch.get_rng_state()
     # The HOST waits for that mark, not the side stream: a stream-side wait on an event of the main stream
     # cost ~45 us of GPU time per pass here (scripts/diag_overlap.py: 0.76 ms per epoch against 0.72), and
     # the host is a pass ahead with this pass's launches already queued, so its wait starves nothing.
     with torch.cuda.stream(side):
-        after = _issue_phase_a(plan, other, bank, before, host_wait=plan["steps_done"][other])
+        after = _issue_phase_a(nplan, other, bank, before, host_wait=nplan.setdefault("steps_done", [None, None])[other])
         done = torch.cuda.Event()
         done.record(side)
     if after is None:                                   # torch drew for us and moved its generator: undo, no speculation
         torch.set_rng_state(before)
-    plan["ahead"] = {"turn": other, "before": before, "after": after, "done": done, "bank": bank}
+    nplan["ahead"] = {"turn": other, "before": before, "after": after, "done": done, "bank": bank}
 
 
 def train(model, train_loader, optimizer, device, args):
@@ -342,6 +373,7 @@ def train(model, train_loader, optimizer, device, args):
         model.train()
     use = engine.train_use_bits(args.discard_classifiers)
     if isinstance(train_loader, ResidentBags):
+        _loader_seed_draw(train_loader)
         batch, lab, bank = _resident_pass_setup(train_loader, device, args)      # phase A issued (or adopted)
         meta = MetaState(model, optimizer)
         engine.train_steps(batch, meta, lab, 0, batch.n_slides, use)
@@ -453,7 +485,59 @@ def _eval_batches(loader, device, args, mode):
     return bank, out
 
 
+def _loader_seed_draw(loader):
+    """What `DataLoader.__iter__` takes from the CPU default generator before the first item (its base seed)."""
+    if isinstance(loader, ResidentBags) and loader.loader_seed_draw:
+        torch.empty((), dtype=torch.int64).random_()
+
+
+_ext_as_bank = {}
+
+
+def _ext_logits_bank(X, device):
+    """A bank whose "foreground" columns are ALL of zeroshot_weights_ext (plus one zero background column, which the
+    bank layout needs): after batch.scores(bank), stats[:Ce] is `feats @ zeroshot_weights_ext` (main_moc.py:428)."""
+    We = zeroshot_weights_ext
+    key = (We.data_ptr(), We._version, tuple(We.shape))
+    pad = _ext_as_bank.get(key)
+    if pad is None:
+        _ext_as_bank.clear()
+        pad = _ext_as_bank[key] = torch.cat([We, torch.zeros_like(We[:, :1])], 1).contiguous()
+    return Bank.get(We, pad, X.dtype, device)
+
+
+def _eval_pass_custom(loader, device, args, pooling_func):
+    """zs_evaluation with a pooling function that is not one of this package's four: the reference calls anything
+    else as `pooling_func(feats @ zeroshot_weights_ext, [args.topk], coords_list=args.n_classes)[1][args.topk]`
+    (main_moc.py:431-432).  The logits are formed by the score kernel, slide-batched; the callable then runs per
+    slide on the device tensor, as it would in the reference."""
+    _loader_seed_draw(loader)
+    X, sizes, x_starts, labels = _collect(loader, device, args)
+    bank = _ext_logits_bank(X, device)
+    Ce = bank.C
+    outs = []
+    for ids in _chunks(sizes, X.size(1), X.element_size()):
+        batch = _sub_batch(X, sizes, x_starts, ids, bank.C, bank.Ce, args.topj, args.topk, [])
+        batch.scores(bank)
+        tensors, _ = batch.meta_ws()
+        rows = []
+        for b in range(len(ids)):
+            o, n = batch.row_off_host[b], batch.sizes[b]
+            logits_ext = batch.stats[:Ce, o:o + n].t().contiguous()
+            rows.append(pooling_func(logits_ext, [args.topk], coords_list=args.n_classes)[1][args.topk].reshape(1, -1))
+        pooled = torch.cat(rows, 0).to(torch.float32).contiguous()
+        lab = torch.tensor([labels[i] for i in ids], dtype=torch.int64).to(device)
+        loss = torch.empty(len(ids), dtype=torch.float32, device=device)
+        pred = torch.empty(len(ids), dtype=torch.int32, device=device)
+        engine.check(engine.lib().moc_ce_loss(engine.ptr(pooled), engine.ptr(lab), len(ids), pooled.size(1),
+                                              engine.ptr(loss), engine.ptr(pred), engine._stream()), "moc_ce_loss")
+        outs.append(torch.cat([pooled, loss.unsqueeze(1)], 1).cpu())
+    allv = torch.cat(outs, 0)
+    return allv[:, :-1].contiguous(), labels, allv[:, -1].tolist()
+
+
 def _eval_pass(loader, device, args, mode, model=None, pooling_func=None):
+    _loader_seed_draw(loader)
     bank, batches = _eval_batches(loader, device, args, mode)
     C_ = bank.C
     meta = MetaState(model) if model is not None else None
@@ -498,10 +582,11 @@ def zs_evaluation(loader, device, args, pooling_func=topj_pooling):
         loader.dataset.repeat_num = real_len
         kinds = {topj_pooling: "topj", delta_softmax_classifier_pooling: "delta_softmax",
                  delta_diff_classifier_pooling: "delta_diff", bottomk_irrel_classifier_pooling: "bottomk"}
-        if pooling_func not in kinds:
-            raise NotImplementedError("zs_evaluation: pooling_func must be one of moc_amd.patch_selection_classifier's four")
         try:
-            pooled, labels, losses = _eval_pass(loader, device, args, "zs_" + kinds[pooling_func])
+            if pooling_func in kinds:
+                pooled, labels, losses = _eval_pass(loader, device, args, "zs_" + kinds[pooling_func])
+            else:           # any other callable, as the reference accepts (main_moc.py:429-432)
+                pooled, labels, losses = _eval_pass_custom(loader, device, args, pooling_func)
         finally:
             loader.dataset.repeat_num = set_len
     return _metrics(pooled, labels, losses, len(loader.dataset), real_len, args)

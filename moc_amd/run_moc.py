@@ -61,6 +61,8 @@ def get_args(argv=None):
     p.add_argument("--root", type=str, default=".", help="directory holding dataset_csv/, splits/, data/, models/")
     p.add_argument("--bag_dtype", type=str, default="fp32", choices=["fp32", "bf16", "fp16"], help="bag storage in HBM")
     p.add_argument("--resident", type=int, default=1, help="keep each split packed in HBM across epochs")
+    p.add_argument("--loader_seed_draw", type=int, default=0,
+                   help="resident splits make the base-seed draw a DataLoader makes per pass (the reference's exact mask stream)")
     p.add_argument("--epochs", type=int, default=25, help="main_moc.py:611 hard-codes 25")
     p.add_argument("--synthetic", type=int, default=0, help="run on N generated slides per split instead of files")
     p.add_argument("--seed", type=int, default=None, help="torch.manual_seed before building the meta-learner")
@@ -169,7 +171,8 @@ def prepare(args, device):
         sp.load_full_path(True)
         sp.load_from_h5(True)
         if args.resident:
-            loaders.append(to_resident(sp, device, {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.bag_dtype)))
+            loaders.append(to_resident(sp, device, {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.bag_dtype),
+                                       loader_seed_draw=bool(args.loader_seed_draw)))
         else:
             loaders.append(torch.utils.data.DataLoader(sp, batch_size=1, shuffle=False, num_workers=1))
     return loaders

@@ -21,13 +21,17 @@ def _free_port():
 
 
 SIZES = [900, 1100, 1000, 800, 950, 1050, 700, 1200, 850, 1150, 990, 760]      # world x T slides: step t uses slides [t*world, (t+1)*world)
+# rank 0's bags all <= 4096 rows, rank 1's all above, with topj (2C + 2) = 7200 > 4096: taken per rank, the step-kernel
+# choice would differ (narrow on rank 0, wide on rank 1) and the in-kernel exchange would pair up the wrong workgroups
+SIZES_SPLIT = [3000, 5200, 3500, 4500, 2800, 6000]
+SHAPES = {"std": (SIZES, 100, 10), "split": (SIZES_SPLIT, 400, 5)}
 
 
-def _steps(world):
-    return len(SIZES) // world
+def _steps(world, sizes=SIZES):
+    return len(sizes) // world
 
 
-def _worker(rank, world, port, q, exchange, C):
+def _worker(rank, world, port, q, exchange, C, shape="std"):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                           MOC_DP_EXCHANGE=exchange, MOC_P2P_TIMEOUT_MS="20000")
@@ -37,11 +41,10 @@ def _worker(rank, world, port, q, exchange, C):
         torch.set_num_threads(2)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dev = torch.device("cuda:0")
-        j, K = 100, 10
+        sizes, j, K = SHAPES[shape]
         W, We = synth.make_bank(77, 512, C)
-        sizes = SIZES
         bags, labels = synth.make_slide_set(7700, sizes, 512, We, C)
-        T = _steps(world)
+        T = _steps(world, sizes)
         mine = [rank + world * t for t in range(T)]               # step t uses slide t of every rank
         torch.manual_seed(5)
         model = M.senet(512, 4).to(dev)
@@ -54,7 +57,7 @@ def _worker(rank, world, port, q, exchange, C):
         assert mdist.exchange_error() == 0
         losses = mdist.train_dp.last[0].meta_ws()[0]["loss"].cpu().numpy()
         ev = None
-        if C <= len(SIZES):          # the AUC needs every class among the slides (sklearn's rule, the reference's too)
+        if C <= len(sizes):          # the AUC needs every class among the slides (sklearn's rule, the reference's too)
             ev = mdist.evaluation_dp(model, res, dev, H.make_args(C, j, K), labels, mine,
                                      [[r + world * t for t in range(T)] for r in range(world)])
         q.put((rank, (H.flat_params(model), losses, ev, int(float(opt.state[next(model.parameters())]["step"])),
@@ -66,15 +69,17 @@ def _worker(rank, world, port, q, exchange, C):
         q.put((rank, "ERR " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("exchange,world,C", [("auto", 2, 2), ("rccl", 2, 2), ("auto", 4, 2), ("auto", 2, 30), ("rccl", 2, 30)])
-def test_train_dp_matches_minibatch_oracle(gpu_device, exchange, world, C):
+@pytest.mark.parametrize("exchange,world,C,shape", [("auto", 2, 2, "std"), ("rccl", 2, 2, "std"), ("auto", 4, 2, "std"),
+                                                     ("auto", 2, 30, "std"), ("rccl", 2, 30, "std"), ("auto", 2, 8, "split")])
+def test_train_dp_matches_minibatch_oracle(gpu_device, exchange, world, C, shape):
     import helpers as H
     from moc_amd import synth
     from oracle import moc_oracle as O
     ctx = mp.get_context("spawn")
     q, port = ctx.Queue(), _free_port()
-    T = _steps(world)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, C)) for r in range(world)]
+    sizes, j, K = SHAPES[shape]
+    T = _steps(world, sizes)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, C, shape)) for r in range(world)]
     for p in procs:
         p.start()
     out = dict(q.get(timeout=300) for _ in range(world))
@@ -89,9 +94,7 @@ def test_train_dp_matches_minibatch_oracle(gpu_device, exchange, world, C):
         # the path asked for is the path taken (auto = the in-kernel exchange on one node)
         assert out[r][4] == ("p2p" if exchange == "auto" else "collective")
     # oracle: T synchronous steps, each the mean gradient of one slide per rank
-    j, K = 100, 10
     W, We = synth.make_bank(77, 512, C)
-    sizes = SIZES
     bags, labels = synth.make_slide_set(7700, sizes, 512, We, C)
     masks = {}
     for rank in range(world):
@@ -118,7 +121,7 @@ def test_train_dp_matches_minibatch_oracle(gpu_device, exchange, world, C):
         np.testing.assert_allclose(out[rank][1], [ref_losses[rank + world * t] for t in range(T)], atol=1e-4)
     H.assert_adam_params_close(out[0][0], H.flat_params(ref), H.flat_state(ropt, "exp_avg_sq"), step=T,
                                grad_noise=1e-6, what=f"dp{world}")
-    if C > len(SIZES):
+    if C > len(sizes):
         return
     ev_ref = O.evaluation(ref, bags, labels, W, We, C, j, K)
     for rank in range(world):

@@ -106,13 +106,16 @@ def test_file_backed_dataloader_equals_resident(gpu_device, tmp_path):
         model = M.senet(512, 4).to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
         tr.repeat_num = rep
-        loader = torch.utils.data.DataLoader(tr, batch_size=1, shuffle=False, num_workers=0) if mode == "loader" else DS.to_resident(tr, dev)
-        vloader = torch.utils.data.DataLoader(va, batch_size=1, shuffle=False, num_workers=0) if mode == "loader" else DS.to_resident(va, dev)
+        # loader_seed_draw: the resident split makes the draw DataLoader.__iter__ makes for its base seed, every pass
+        loader = (torch.utils.data.DataLoader(tr, batch_size=1, shuffle=False, num_workers=0) if mode == "loader"
+                  else DS.to_resident(tr, dev, loader_seed_draw=True))
+        vloader = (torch.utils.data.DataLoader(va, batch_size=1, shuffle=False, num_workers=0) if mode == "loader"
+                   else DS.to_resident(va, dev, loader_seed_draw=True))
         torch.manual_seed(77)
         for _ in range(2):
-            if mode == "resident":
-                torch.empty((), dtype=torch.int64).random_()      # what DataLoader.__iter__ draws for its base seed
             M.train(model, loader, opt, dev, args)
-        out.append((H.flat_params(model), M.evaluation(model, vloader, dev, args)))
+            mid = M.evaluation(model, vloader, dev, args)          # (an evaluation between the passes draws too)
+        out.append((H.flat_params(model), mid, M.evaluation(model, vloader, dev, args), torch.get_rng_state()))
     np.testing.assert_array_equal(out[0][0], out[1][0])
-    assert out[0][1] == out[1][1]
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    assert torch.equal(out[0][3], out[1][3]), "the two paths leave the CPU generator in different states"

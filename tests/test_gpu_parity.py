@@ -492,6 +492,14 @@ def test_evaluations_match_reference_fixtures(dev):
             loader = H.ListLoader(bags, labels, rn)
             close(M.zs_evaluation(loader, dev, args, pooling_func=fn), g[f"c{cid}_zs_{name}"], "zs " + name)
             assert loader.dataset.repeat_num == rn
+        # any OTHER callable is called as the reference calls it (main_moc.py:431-432): on feats @ zeroshot_weights_ext
+        # with coords_list=n_classes -- here a wrapper around the bottom-k pooling, which must land on the same fixture
+        def custom(logits_ext, topj, **kw):
+            assert logits_ext.is_cuda and logits_ext.shape == (N, C + 4) and kw == {"coords_list": C}
+            return P.bottomk_irrel_classifier_pooling(logits_ext, topj, **kw)
+        loader = H.ListLoader(bags, labels, rn)
+        close(M.zs_evaluation(loader, dev, args, pooling_func=custom), g[f"c{cid}_zs_bottomk"], "zs custom callable")
+        assert loader.dataset.repeat_num == rn
         for mode in ("avg", "sum", "max"):
             args.ablation_study = mode
             close(M.ablation_evaluation(H.ListLoader(bags, labels, rn), dev, args), g[f"c{cid}_abl_{mode}"], "ablation " + mode)

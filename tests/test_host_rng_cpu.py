@@ -56,3 +56,16 @@ def test_falls_back_under_float64_default():
         assert torch.equal(ref, got.bool())
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+def test_rejects_a_state_with_nothing_left():
+    """`left` == 0 never leaves at::mt19937 (it regenerates AT zero); the replay refuses it instead of indexing
+    before its output (the caller then lets torch draw)."""
+    import ctypes as C
+    from moc_amd._lib import lib, ptr
+    torch.manual_seed(11)
+    st = torch.get_rng_state()
+    st[8:12] = 0                                    # i32 left = 0
+    out = torch.empty(16, dtype=torch.uint8)
+    assert lib().moc_host_draw_masks(ptr(st), st.numel(), 16, ptr(out)) < 0
+    assert b"unexpected generator state" in C.cast(lib().moc_last_error(), C.c_char_p).value
