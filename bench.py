@@ -88,6 +88,8 @@ def parse():
                          "weak = every rank its own --slides slides")
     ap.add_argument("--no-dp-extra", action="store_true", help="N > 1, seq: skip the minibatch_dp extra block")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel trainer even at 1 GPU (rehearsal)")
+    ap.add_argument("--force-seq", action="store_true", help="run the exact-sequential multi-GPU trainer even at 1 GPU "
+                                                              "(rehearsal: what its pack / gather / compact-batch machinery costs)")
     return ap.parse_args()
 
 
@@ -370,7 +372,7 @@ def main():
 
     engine.SCORE_EVENTS = []          # (start, stop, algorithmic bytes) per score-pass launch
     if world == 1:
-        main_mode = "dp_weak" if a.force_dp else "single"
+        main_mode = "dp_weak" if a.force_dp else "seq" if a.force_seq else "single"
     else:
         main_mode = "seq" if a.train_mode == "seq" else "dp_" + a.scaling
     r = measure(main_mode, a.steps, a.warmup, 0 if a.no_steady else a.steady_epochs)
@@ -471,7 +473,7 @@ def main():
 
     # ---- CPU baseline: the oracle's train loop on the host cores (rank 0, N=1 only)
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu:
+    if rank == 0 and world == 1 and not a.no_cpu and isinstance(res, M.ResidentBags):
         from oracle import moc_oracle as O
         labels = res.labels
         cpu_bags = [res.X[res.starts[i]:res.starts[i + 1]].to(torch.float32).cpu() for i in range(a.slides)]
@@ -500,7 +502,7 @@ def main():
                          f"(fp32 copies of the bag values, torch-CPU oracle, {threads} threads)"}
 
     if rank == 0:
-        if world == 1:
+        if world == 1 and main_mode != "seq":
             par = "single GPU, one Adam step per slide"
         elif main_mode == "seq":
             par = (f"seq{world}: exact-sequential -- bags and phase A (mask, scores, selectors, union) sharded over the {world} GPUs "

@@ -155,15 +155,13 @@ __device__ __forceinline__ void row_epilogue(const ScoresArgs& a, const float* t
 // all 64 lanes: lane = (part, row) with part = lane >> 4 owning columns part, part + 4, ...; the row's
 // values are read from the wave's tile in one batch of independent LDS reads, the four partial results of
 // a row meet through two xor-shuffles (commutative pairings: every lane of a row gets the same bits)
-template <int NT>
-__device__ __forceinline__ void row_epilogue_wide(const ScoresArgs& a, const float* tile, int64_t slot_base,
-                                                  int row0, int nk) {
-    constexpr int LDT = NT * 16 + 1, Q = NT * 4;
+// The statistics of one row from its Q*4 column values spread over the row's four lanes (lane = (part, row), part owning
+// columns part, part + 4, ...): the four partial results meet through two xor-shuffles (commutative pairings: every
+// lane of a row gets the same bits).
+template <int Q>
+__device__ __forceinline__ void row_stats_emit(const ScoresArgs& a, const float (&v)[Q], int64_t slot_base, int row0, int nk) {
     const int lane = threadIdx.x & 63, row = lane & 15, part = lane >> 4;
     const int C = a.C, Ce = a.Ce;
-    float v[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) v[q] = tile[row * LDT + q * 4 + part];
     float m1 = -INFINITY, m2 = -INFINITY, bsum = 0.f, bmax = -INFINITY;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -205,6 +203,18 @@ __device__ __forceinline__ void row_epilogue_wide(const ScoresArgs& a, const flo
     else if (part == 1) s[(int64_t)(2 * C + 1) * a.stride] = bsum;
     else if (part == 2) s[(int64_t)(2 * C + 2) * a.stride] = bmax;
     else a.sel_flag[slot_base + row0 + row] = 0;
+}
+
+// all 64 lanes: the row's values are read from the wave's 16 x (NT*16) tile in one batch of independent LDS reads
+template <int NT>
+__device__ __forceinline__ void row_epilogue_wide(const ScoresArgs& a, const float* tile, int64_t slot_base,
+                                                  int row0, int nk) {
+    constexpr int LDT = NT * 16 + 1, Q = NT * 4;
+    const int lane = threadIdx.x & 63, row = lane & 15, part = lane >> 4;
+    float v[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[q] = tile[row * LDT + q * 4 + part];
+    row_stats_emit<Q>(a, v, slot_base, row0, nk);
 }
 
 // CH = elements of K held in registers per chunk (512 or 256).  BF16: bf16 bag.

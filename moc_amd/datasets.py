@@ -167,6 +167,34 @@ def to_resident(split: Generic_Split, device, dtype=None, loader_seed_draw=False
                         loader_seed_draw=loader_seed_draw)
 
 
+def to_sharded(split: Generic_Split, device, rank: int, world: int, dtype=None, train=False, group=None):
+    """Multi-GPU form of to_resident: this rank reads ONLY the contiguous block of slides it will hold and keeps it
+    packed in HBM -> moc_amd.dist.ShardedSplit (`train`: a SeqShardedBags for dist.train_seq, which also needs every
+    slide's row count -- exchanged once through the process group)."""
+    import torch.distributed as dist
+    from . import dist as mdist
+    n = split.real_len()
+    labels = [int(v) for v in split.slide_data["label"]]
+    blocks = mdist.block_lists(n, world)
+    bags, paths = [], []
+    for i in blocks[rank]:
+        feats, coords, path = read_bag(split.data_dir, split.slide_data["slide_id"][i])
+        bags.append(feats.to(torch.float32))
+        paths.append(path)
+    if not train:
+        return mdist.ShardedSplit(bags, blocks[rank], labels, blocks, device, dtype=dtype, paths=paths)
+    box = [None] * world
+    dist.all_gather_object(box, [int(b.size(0)) for b in bags], group=group)
+    sizes = [v for part in box for v in part]
+    sh = mdist.SeqShardedBags(bags, sizes, labels, device, rank, world, dtype=dtype, paths=paths)
+    if split.repeat_num and split.repeat_num != n:
+        if split.repeat_num > n:
+            raise NotImplementedError("multi-GPU training visits every slide at most once per epoch "
+                                      f"(repeat_num {split.repeat_num} > {n} slides in the split)")
+        sh.repeat_num = split.repeat_num
+    return sh
+
+
 def write_bag(data_dir: str, slide_id: str, features: torch.Tensor, coords=None, fmt="pt"):
     """Test/demo helper: store one bag in one of the layouts read_bag understands."""
     feats = features.detach().cpu().to(torch.float32)

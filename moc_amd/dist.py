@@ -120,6 +120,7 @@ class P2pExchange:
         self.C, self.lib, self.check = C, lib(), check
         self.handle = C.c_void_p()
         self.ok = False
+        self.step_checked = False
         self.why = ""
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -171,6 +172,96 @@ class P2pExchange:
     def all_reduce_(self, flat: torch.Tensor):
         self.check(self.lib.moc_p2p_allreduce(self.handle, flat.data_ptr(), flat.numel(),
                                               torch.cuda.current_stream().cuda_stream), "moc_p2p_allreduce")
+
+    def step_self_check(self, device, bank, topj: int, topk: int, group=None) -> bool:
+        """Collective.  The set-up check above runs p2p_allreduce_kernel; what training runs is the STEP kernel's own
+        push / flag / sum path (pool_w1_step_kernel or its wide form, chosen from the run's constants).  So before
+        train_dp trusts the exchange: two synchronous steps of the real step kernel -- both buffer parities -- on two
+        small synthetic slides per rank, the last rank deliberately late at the second step, compared with the same two
+        steps taken the slow way: every rank's gradient (moc_train_grad) all-gathered through torch.distributed, summed
+        in rank order (the order p2p_sum uses) and applied by moc_adam_step.  All ranks must hold the same bits and
+        match that expectation to 1e-6; any doubt on any rank sends ALL ranks to the collective path."""
+        import time
+        from . import engine, main_moc as M
+        world, rank = self.world, self.rank
+        D, C_, Ce = bank.D, bank.C, bank.Ce
+        verdict = 0
+        try:
+            g = torch.Generator(device="cpu")
+            g.manual_seed(97)                                   # same meta-learner on every rank, torch's own RNG untouched
+
+            def fresh():
+                m = M.senet(D, 4)
+                with torch.no_grad():
+                    for p_ in m.parameters():
+                        p_.copy_(torch.randn(p_.shape, generator=g) * 0.05)
+                m = m.to(device)
+                return m, torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4)
+            model_a, opt_a = fresh()
+            g.manual_seed(97)
+            model_b, opt_b = fresh()
+            gx = torch.Generator(device="cpu")
+            gx.manual_seed(1000 + rank)                         # different slides on every rank
+            sizes = [700 + 37 * rank, 650 + 11 * rank]
+            X = torch.randn(sum(sizes), D, generator=gx)
+            X = (X / X.norm(dim=1, keepdim=True)).to(bank.dtype).to(device)
+            batch = engine.SlideBatch(X, sizes, C_, Ce, topj, topk)
+            batch.phase_a(bank)
+            lab = torch.tensor([rank % C_, (rank + 1) % C_], dtype=torch.int64, device=device)
+            use = 15
+            # (a) the step kernel's exchange, one step per call so that a rank can be late between them
+            meta_a = engine.MetaState(model_a, opt_a)
+            engine.train_steps_p2p(batch, meta_a, lab, 0, 1, use, self.handle)
+            meta_a.advance(1)
+            torch.cuda.synchronize()
+            if rank == world - 1:
+                time.sleep(0.25)                                # the others' step kernels wait in their bounded polls
+            engine.train_steps_p2p(batch, meta_a, lab, 1, 1, use, self.handle)
+            meta_a.advance(1)
+            # (b) the same two steps through torch.distributed
+            meta_b = engine.MetaState(model_b, opt_b, need_grads=True)
+            fg = FlatGrads(meta_b.params, device)
+            for name, v in zip(("g_W1", "g_b1", "g_W2", "g_b2"), fg.views):
+                setattr(meta_b.c, name, v.data_ptr())
+            for t in range(2):
+                engine.train_grad(batch, meta_b, lab, t, use)
+                parts = [torch.empty_like(fg.flat) for _ in range(world)]
+                dist.all_gather(parts, fg.flat, group=group)
+                total = torch.zeros_like(fg.flat)
+                for q in range(world):                          # rank order, as p2p_sum
+                    total += parts[q]
+                fg.flat.copy_(total)
+                engine.adam_step(meta_b, grad_scale=1.0 / world)
+            torch.cuda.synchronize()
+            pa = torch.cat([p_.detach().reshape(-1) for p_ in model_a.parameters()])
+            pb = torch.cat([p_.detach().reshape(-1) for p_ in model_b.parameters()])
+            close = bool(torch.isfinite(pa).all()) and float((pa - pb).abs().max()) <= 1e-6
+            # the same bits on every rank: compare a checksum of the raw words
+            h = pa.view(torch.int32).to(torch.int64)
+            sig = torch.stack([h.sum(), (h * torch.arange(1, h.numel() + 1, device=device)).sum()])
+            lo, hi = sig.clone(), sig.clone()
+            if dist.get_backend(group) != "nccl":
+                lo, hi = lo.cpu(), hi.cpu()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+            verdict = int(close and torch.equal(lo, hi) and self.error() == 0)
+            if not verdict:
+                self.why = (f"step-kernel self-check: max |p2p - gathered| = {float((pa - pb).abs().max()):.3e}, "
+                            f"ranks agree = {bool(torch.equal(lo, hi))}, error word = {self.error()}")
+        except Exception as e:  # noqa: BLE001 (set-up only)
+            self.why = f"step-kernel self-check raised: {e}"
+            verdict = 0
+        flag = torch.tensor([verdict], dtype=torch.int32, device=device)
+        if dist.get_backend(group) != "nccl":
+            flag = flag.cpu()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        self.step_checked = True
+        if int(flag.item()) != 1:
+            self.ok = False
+            import warnings
+            warnings.warn(f"peer-to-peer gradient exchange failed its step-kernel self-check ({self.why or 'on another rank'}); "
+                          "using the collective")
+        return self.ok
 
     def error(self) -> int:
         return int(self.lib.moc_p2p_error(self.handle))
@@ -352,6 +443,10 @@ def train_dp(model, loader, optimizer, device, args, group=None):
     # the step kernel (moc_train_steps_p2p: forward + step, two launches); otherwise per step
     # forward, pool+loss+gradients, the ONE collective (the flat gradient), Adam with 1/world.
     x = p2p_exchange(device, fg.flat.numel(), group) if (fg.flat.is_cuda and engine.fused_step_shape(batch)) else None
+    if x is not None and not x.step_checked:
+        # first use with this shape: the step kernel's own exchange path must reproduce a gathered sum (collective)
+        if not x.step_self_check(device, bank, args.topj, args.topk, group):
+            x = None
     if x is not None:
         if x.error():
             raise RuntimeError(f"peer-to-peer exchange: rank {x.error() - 1} stayed silent past the time-out in an earlier pass")
@@ -368,36 +463,103 @@ def train_dp(model, loader, optimizer, device, args, group=None):
     train_dp.last = (batch, lab, fg)
 
 
+# --------------------------------------------------------------------------- splits spread over the ranks
+def block_lists(n_items: int, world: int):
+    """Contiguous blocks of the loader order, one per rank (the last ones may be short or empty)."""
+    per = (n_items + world - 1) // world
+    return [list(range(min(n_items, r * per), min(n_items, (r + 1) * per))) for r in range(world)]
+
+
+class ShardedSplit:
+    """One split of a run spread over the ranks of a process group: every rank knows every slide's label (and which
+    rank holds it); the bags of `my_ids` live here, packed in HBM (`local`, a main_moc.ResidentBags, or None when this
+    rank holds none).  Offers what main_moc's loops ask of `loader.dataset` (real_len(), repeat_num, len()).  The
+    evaluation loops below take it where main_moc's take a loader."""
+
+    def __init__(self, my_bags, my_ids, all_labels, index_lists, device, dtype=None, paths=None):
+        from . import main_moc as M
+        self.all_labels = [int(v) for v in all_labels]
+        self.my_ids = [int(i) for i in my_ids]
+        self.index_lists = [[int(i) for i in lst] for lst in index_lists]
+        assert sorted(i for lst in self.index_lists for i in lst) == list(range(len(self.all_labels))), "shards do not partition the slides"
+        assert len(my_bags) == len(self.my_ids)
+        self.device = torch.device(device)
+        self.local = (M.ResidentBags(my_bags, [self.all_labels[i] for i in self.my_ids], device, dtype=dtype, paths=paths)
+                      if len(my_bags) else None)
+        self.repeat_num = None
+        self.dataset = self
+
+    def real_len(self):
+        return len(self.all_labels)
+
+    def __len__(self):
+        return self.repeat_num if self.repeat_num else len(self.all_labels)
+
+
+def _eval_sharded(split: ShardedSplit, device, args, mode, model=None, pooling_func=None, group=None):
+    """Every rank runs main_moc's batched evaluation pass over ITS slides; one all_gather of the [n_local, C + 1]
+    (pooled logits | loss) rows; the reference's metrics over all slides, the same dict on every rank."""
+    from . import main_moc as M
+    real_len = split.real_len()
+    n_div = len(split)                      # main_moc.py:499-501: the loss is divided by len(dataset) as the caller left it
+    C_ = args.n_classes
+    with torch.no_grad():
+        if split.local is not None:
+            split.local.repeat_num = None
+            if mode == "zs_custom":
+                pooled, _, losses = M._eval_pass_custom(split.local, device, args, pooling_func)
+            else:
+                pooled, _, losses = M._eval_pass(split.local, device, args, mode, model=model)
+            both = torch.cat([pooled.to(device), torch.tensor(losses, dtype=torch.float32, device=device).unsqueeze(1)], 1)
+        else:
+            both = torch.zeros((0, C_ + 1), dtype=torch.float32, device=device)
+    counts = [len(lst) for lst in split.index_lists]
+    allv = unshard(gather_rows(both, counts, group), split.index_lists, real_len).cpu()
+    return M._metrics(allv[:, :-1].contiguous(), list(split.all_labels), allv[:, -1].tolist(), n_div, real_len, args)
+
+
+def evaluation(model, split: ShardedSplit, device, args, group=None):
+    """main_moc.evaluation (main_moc.py:462-520) over a split spread across the ranks."""
+    if model.training:
+        model.eval()
+    return _eval_sharded(split, device, args, "eval", model=model, group=group)
+
+
+def zs_evaluation(split: ShardedSplit, device, args, pooling_func=None, group=None):
+    """main_moc.zs_evaluation (main_moc.py:412-460) over a split spread across the ranks."""
+    from . import patch_selection_classifier as P
+    kinds = {None: "topj", P.topj_pooling: "topj", P.delta_softmax_classifier_pooling: "delta_softmax",
+             P.delta_diff_classifier_pooling: "delta_diff", P.bottomk_irrel_classifier_pooling: "bottomk"}
+    if pooling_func in kinds:
+        return _eval_sharded(split, device, args, "zs_" + kinds[pooling_func], group=group)
+    return _eval_sharded(split, device, args, "zs_custom", pooling_func=pooling_func, group=group)
+
+
+def ablation_evaluation(split: ShardedSplit, device, args, group=None):
+    """main_moc.ablation_evaluation (main_moc.py:523-582) over a split spread across the ranks."""
+    return _eval_sharded(split, device, args, "ablation", group=group)
+
+
 # --------------------------------------------------------------------------- exact-sequential multi-GPU (section 8e mode 1)
-class SeqShardedBags:
+class SeqShardedBags(ShardedSplit):
     """A train split whose slides live on G GPUs -- rank r holds the contiguous block [r*per, (r+1)*per) of the
     loader order -- for train_seq.  Every rank knows every slide's size and label (the mask stream and the labels
-    are global); only the bag rows are sharded.  Offers what main_moc's loops ask of a loader's dataset
-    (real_len(), repeat_num, len())."""
+    are global); only the bag rows are sharded.  Being a ShardedSplit it can also be evaluated (main_moc.py:615
+    evaluates the train split every epoch)."""
 
-    def __init__(self, my_bags, all_sizes, all_labels, device, rank: int, world: int, dtype=None):
-        from . import main_moc as M
+    def __init__(self, my_bags, all_sizes, all_labels, device, rank: int, world: int, dtype=None, paths=None):
         self.all_sizes = [int(v) for v in all_sizes]
-        self.all_labels = [int(v) for v in all_labels]
         n = len(self.all_sizes)
-        assert len(self.all_labels) == n and n >= 1
+        assert len(all_labels) == n and n >= 1
         self.rank, self.world = int(rank), int(world)
         self.per = (n + world - 1) // world
+        blocks = block_lists(n, world)
         self.lo, self.hi = min(n, rank * self.per), min(n, (rank + 1) * self.per)
         assert len(my_bags) == self.hi - self.lo, f"rank {rank} holds slides [{self.lo}, {self.hi}) of the loader order"
         assert [int(b.size(0)) for b in my_bags] == self.all_sizes[self.lo:self.hi]
-        self.local = M.ResidentBags(my_bags, self.all_labels[self.lo:self.hi], device, dtype=dtype) if my_bags else None
-        self.device = torch.device(device)
-        self.repeat_num = None
+        super().__init__(my_bags, blocks[rank], all_labels, blocks, device, dtype=dtype, paths=paths)
         self.next_pass_len = None
-        self.dataset = self
         self._plans = {}
-
-    def real_len(self):
-        return len(self.all_sizes)
-
-    def __len__(self):
-        return self.repeat_num if self.repeat_num else len(self.all_sizes)
 
 
 def _seq_plan(sh: SeqShardedBags, m: int, bank, args):

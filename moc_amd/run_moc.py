@@ -5,6 +5,7 @@ around the GPU callables of moc_amd.main_moc.
     python -m moc_amd.run_moc --fold 0 --shot 16 --topj 400 --topk 10 --dataset nsclc
     python -m moc_amd.run_moc --summary --summary_dir results/moc_train/nsclc
     python -m moc_amd.run_moc --synthetic 24 --shot 4 --disable_tqdm        # no data needed
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m moc_amd.run_moc ...   # 8 GPUs
 
 Same flags and defaults as the reference, same result files (`zs_results_*`, `best_results_*`,
 `ablation_results_*`, `best_model_*.pt`, `summary_*.csv`) with the same keys.  Differences, all
@@ -13,6 +14,12 @@ CONCH text tower is not part of this path, so the zero-shot weights must already
 `models/classifier_weights/` (the reference caches them there on first run, main_moc.py:149-197);
 `--bag_dtype bf16|fp16` stores bags as bfloat16 / float16; `--resident 0` falls back to per-epoch re-reads;
 `--synthetic N` runs the whole loop on N generated slides per split.
+
+Under a launcher (WORLD_SIZE > 1) every split is spread over the GPUs (each rank reads only its block of slides):
+training is the exact-sequential mode -- phase A where the bags are, the compact results all-gathered, the reference's
+one-Adam-step-per-slide recurrence on every rank (moc_amd.dist.train_seq: the numbers of a one-GPU run, bit for bit) --
+and the evaluations shard by slide with one gather of the pooled logits (moc_amd.dist.evaluation).  Rank 0 prints and
+writes the result files.
 """
 from __future__ import annotations
 
@@ -25,8 +32,9 @@ import numpy as np
 import pandas as pd
 import torch
 
+from . import dist as mdist
 from . import main_moc as M
-from .datasets import Generic_MIL_Dataset, to_resident
+from .datasets import Generic_MIL_Dataset, to_resident, to_sharded
 
 # dataset -> (csv, split dir, label map, weight file stems)   main_moc.py:161-293
 TASKS = {
@@ -135,7 +143,11 @@ def _load_weights(args, task, device):
 
 
 def prepare(args, device):
-    """-> (train_loader, val_loader, test_loader) and the classifier bank installed in moc_amd.main_moc."""
+    """-> (train_loader, val_loader, test_loader) and the classifier bank installed in moc_amd.main_moc.  Inside a
+    process group of more than one rank the three are moc_amd.dist.ShardedSplit objects (each rank holds its block)."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
     if args.synthetic:
         from . import synth
         C = 2 if args.dataset == "nsclc" else 3 if args.dataset == "rcc" else 12 if args.dataset == "ebrains12" else 30
@@ -145,7 +157,15 @@ def prepare(args, device):
         dt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.bag_dtype, torch.float32)
         loaders = []
         for s, (base, n, rep) in enumerate(((100, args.shot * C, args.shot * C), (5000, args.synthetic, None), (9000, args.synthetic, None))):
-            bags, labels = synth.make_slide_set(base, synth.bag_sizes(base, n, 3000, fixed=False, lo=500, hi=8000), 512, We, C)
+            sizes = synth.bag_sizes(base, n, 3000, fixed=False, lo=500, hi=8000)
+            if world > 1:                    # every rank generates only the slides of its block (seeds are per slide)
+                blocks = mdist.block_lists(n, world)
+                labels = [i % C for i in range(n)]
+                bags = [synth.make_bag(base + i, sizes[i], 512, We, C, labels[i]) for i in blocks[rank]]
+                loaders.append(mdist.SeqShardedBags(bags, sizes, labels, device, rank, world, dtype=dt) if s == 0 else
+                               mdist.ShardedSplit(bags, blocks[rank], labels, blocks, device, dtype=dt))
+                continue
+            bags, labels = synth.make_slide_set(base, sizes, 512, We, C)
             loaders.append(M.ResidentBags(bags, labels, device, dtype=dt, repeat_num=rep))
         return loaders
     task = TASKS[args.dataset]
@@ -167,10 +187,13 @@ def prepare(args, device):
                                    csv_path=os.path.join(args.root, task["splits"], f"{args.shot}shots", f"splits_{args.fold}.csv"),
                                    repeat_num=int(args.shot) * args.n_classes)
     loaders = []
-    for sp in splits:
+    for s_i, sp in enumerate(splits):
         sp.load_full_path(True)
         sp.load_from_h5(True)
-        if args.resident:
+        if world > 1:
+            loaders.append(to_sharded(sp, device, rank, world, {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.bag_dtype),
+                                      train=(s_i == 0)))
+        elif args.resident:
             loaders.append(to_resident(sp, device, {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.bag_dtype),
                                        loader_seed_draw=bool(args.loader_seed_draw)))
         else:
@@ -179,23 +202,54 @@ def prepare(args, device):
 
 
 # ------------------------------------------------------------------ main (main_moc.py:586-644)
+def _train(model, loader, optimizer, device, args):
+    if isinstance(loader, mdist.SeqShardedBags):
+        return mdist.train_seq(model, loader, optimizer, device, args)
+    return M.train(model, loader, optimizer, device, args)
+
+
+def _evaluation(model, loader, device, args):
+    if isinstance(loader, mdist.ShardedSplit):
+        return mdist.evaluation(model, loader, device, args)
+    return M.evaluation(model, loader, device, args)
+
+
+def _zs_evaluation(loader, device, args):
+    if isinstance(loader, mdist.ShardedSplit):
+        return mdist.zs_evaluation(loader, device, args)
+    return M.zs_evaluation(loader, device, args)
+
+
+def _is_main():
+    import torch.distributed as dist
+    return not dist.is_initialized() or dist.get_rank() == 0
+
+
 def main(args, model, optimizer, train_loader, val_loader, test_loader, device):
-    os.makedirs(args.result_dir, exist_ok=True)
+    """main_moc.py:586-644.  The loaders are anything main_moc's loops take, or moc_amd.dist.ShardedSplit objects
+    (multi-GPU: every rank calls this; rank 0 prints and writes)."""
+    chief = _is_main()
+    say = print if chief else (lambda *a, **k: None)
+    if chief:
+        os.makedirs(args.result_dir, exist_ok=True)
     if args.ablation_study != "none":
-        ablation_eval_dict = M.ablation_evaluation(test_loader, device, args)
-        print(f"Ablation Study: {args.ablation_study}, Test: {ablation_eval_dict}")
-        with open(os.path.join(args.result_dir, f"ablation_results_{args.ablation_study}_shot_{args.shot}_fold_{args.fold}.json"), "w") as f:
-            json.dump(ablation_eval_dict, f, indent=4)
+        ablation_eval_dict = (mdist.ablation_evaluation(test_loader, device, args) if isinstance(test_loader, mdist.ShardedSplit)
+                              else M.ablation_evaluation(test_loader, device, args))
+        say(f"Ablation Study: {args.ablation_study}, Test: {ablation_eval_dict}")
+        if chief:
+            with open(os.path.join(args.result_dir, f"ablation_results_{args.ablation_study}_shot_{args.shot}_fold_{args.fold}.json"), "w") as f:
+                json.dump(ablation_eval_dict, f, indent=4)
         return ablation_eval_dict
 
     zs_train, zs_val, zs_test = -1, -1, -1
     if args.check_zeroshot:
-        zs_train = M.zs_evaluation(train_loader, device, args)
-        zs_val = M.zs_evaluation(val_loader, device, args)
-        zs_test = M.zs_evaluation(test_loader, device, args)
-        print(f"Zero-shot Train: {zs_train}, Val: {zs_val}, Test: {zs_test}")
-        with open(os.path.join(args.result_dir, f"zs_results_shot_{args.shot}_fold_{args.fold}.json"), "w") as f:
-            json.dump({"zs_train": zs_train, "zs_val": zs_val, "zs_test": zs_test}, f, indent=4)
+        zs_train = _zs_evaluation(train_loader, device, args)
+        zs_val = _zs_evaluation(val_loader, device, args)
+        zs_test = _zs_evaluation(test_loader, device, args)
+        say(f"Zero-shot Train: {zs_train}, Val: {zs_val}, Test: {zs_test}")
+        if chief:
+            with open(os.path.join(args.result_dir, f"zs_results_shot_{args.shot}_fold_{args.fold}.json"), "w") as f:
+                json.dump({"zs_train": zs_train, "zs_val": zs_val, "zs_test": zs_test}, f, indent=4)
 
     best_val = 0
     test_at_best_val = 0
@@ -203,30 +257,32 @@ def main(args, model, optimizer, train_loader, val_loader, test_loader, device):
     best_epoch = 0
     model_path = os.path.join(args.result_dir, f"best_model_shot_{args.shot}_fold_{args.fold}.pt")
     for epoch in range(getattr(args, "epochs", 25)):
-        print("Epoch: ", epoch)
-        M.train(model, train_loader, optimizer, device, args)
-        train_eval = M.evaluation(model, train_loader, device, args)
-        val_eval = M.evaluation(model, val_loader, device, args)
+        say("Epoch: ", epoch)
+        _train(model, train_loader, optimizer, device, args)
+        train_eval = _evaluation(model, train_loader, device, args)
+        val_eval = _evaluation(model, val_loader, device, args)
         if val_eval["auc"] > best_val:          # the test split is only visited on improvement (:618-628)
-            test_eval = M.evaluation(model, test_loader, device, args)
-            print(f"Epoch: {epoch}, Train: {train_eval}, Val: {val_eval}, Test: {test_eval}")
+            test_eval = _evaluation(model, test_loader, device, args)
+            say(f"Epoch: {epoch}, Train: {train_eval}, Val: {val_eval}, Test: {test_eval}")
             best_val = val_eval["auc"]
             test_at_best_val = test_eval["auc"]
             test_acc_at_best_val = test_eval["acc"]
             best_epoch = epoch
-            torch.save(model.state_dict(), model_path)
+            if chief:
+                torch.save(model.state_dict(), model_path)
         else:
-            print(f"Epoch: {epoch}, Train: {train_eval}, Val: {val_eval}")
-    print(f"Zero-shot Train: {zs_train}, Val: {zs_val}, Test: {zs_test}")
-    print(f"Best Val: {best_val}, Test at Best Val: {test_at_best_val}, Test acc: {test_acc_at_best_val}, Best Epoch: {best_epoch}")
+            say(f"Epoch: {epoch}, Train: {train_eval}, Val: {val_eval}")
+    say(f"Zero-shot Train: {zs_train}, Val: {zs_val}, Test: {zs_test}")
+    say(f"Best Val: {best_val}, Test at Best Val: {test_at_best_val}, Test acc: {test_acc_at_best_val}, Best Epoch: {best_epoch}")
     results = {
         "zero_shot_train": zs_train, "zero_shot_val": zs_val, "zero_shot_test": zs_test,
         "best_val": best_val, "test_at_best_val": test_at_best_val, "test_acc_at_best_val": test_acc_at_best_val,
         "best_epoch": best_epoch, "best_model_path": model_path,
     }
-    with open(os.path.join(args.result_dir, f"best_results_shot_{args.shot}_fold_{args.fold}.json"), "w") as f:
-        json.dump(results, f, indent=4)
-    print("\nEnd training.")
+    if chief:
+        with open(os.path.join(args.result_dir, f"best_results_shot_{args.shot}_fold_{args.fold}.json"), "w") as f:
+            json.dump(results, f, indent=4)
+    say("\nEnd training.")
     return results
 
 
@@ -237,13 +293,29 @@ def cli(argv=None):
         return None
     if not torch.cuda.is_available():
         raise RuntimeError("moc_amd needs a GPU: there is no CPU fallback")
-    device = torch.device("cuda")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:                                   # one process per GPU under a launcher (torch.distributed.run)
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        device = torch.device("cuda")
     train_loader, val_loader, test_loader = prepare(args, device)
     if args.seed is not None:
         torch.manual_seed(args.seed)
+    elif world > 1:
+        raise SystemExit("multi-GPU runs need --seed: every rank must build the same meta-learner and draw the same masks")
     model = M.senet(512, 4).to(device)                                                   # main_moc.py:315
     optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)         # main_moc.py:316
-    return main(args, model, optimizer, train_loader, val_loader, test_loader, device)
+    try:
+        return main(args, model, optimizer, train_loader, val_loader, test_loader, device)
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            mdist.shutdown()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

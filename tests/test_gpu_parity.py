@@ -640,3 +640,57 @@ def test_train_and_eval_match_oracle_on_odd_shapes(dev, C, K, j, D, dtype, sizes
         ev_ref = O.evaluation(ref_model, ref_bags, labels, W, We, C, j, K)
         ev = M.evaluation(model, res, dev, args)
         assert abs(ev["loss"] - ev_ref["loss"]) < ATOL and ev["acc"] == ev_ref["acc"] and abs(ev["auc"] - ev_ref["auc"]) < 2e-3
+
+
+# ------------------------------------------------------------------ BASELINE.json configs 3 / 4 / 5 at their stated sizes
+@pytest.mark.parametrize("name,C,K,j,D,dtype,sizes", [
+    ("cfg 3, RCC 3-way", 3, 10, 400, 512, torch.bfloat16, [15000, 14000, 16000]),
+    # topj (2C + 2) = 24,800 > every slide: the union is every kept row -- ~7.5 k to 11 k in train (mask), up to
+    # 22,000 in evaluation: beyond 8,192 the pooling is topk_mean_kernel's and the wide step kernel picks it up
+    ("cfg 4, EBRAINS-30 30-way", 30, 10, 400, 512, torch.bfloat16, [15000, 22000, 15000, 19000]),
+    ("cfg 5, 64-way x 1024-d fp16", 64, 10, 400, 1024, torch.float16, [50000, 50000]),
+])
+def test_full_size_wide_configs_match_oracle(dev, name, C, K, j, D, dtype, sizes):
+    """One epoch of train() and one evaluation pass at the sizes BASELINE.json quotes for its wide configurations,
+    against the oracle: per-step losses 1e-4, parameters within the Adam noise bound, pooled evaluation logits 1e-4
+    (the AUC needs every class among the slides, so the comparison is on what the AUC is computed from)."""
+    M = _mm()
+    W, We = synth.make_bank(4400 + C, D, C)
+    bags, labels = synth.make_slide_set(44000 + C, sizes, D, We, C)
+    labels = [(7 * i + 1) % C for i in range(len(sizes))]
+    bags = [b.to(dtype) for b in bags]
+    ref_bags = [b.to(torch.float32) for b in bags]
+    torch.manual_seed(9)
+    ref_model = O.Senet(D, 4)
+    ref_opt = O.make_optimizer(ref_model)
+    torch.manual_seed(9)
+    model = M.senet(D, 4).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    M.set_classifier_bank(W.to(dev), We.to(dev))
+    args = H.make_args(C, j, K)
+    res = M.ResidentBags(bags, labels, dev)
+    torch.manual_seed(77)
+    ref_losses = O.train_epoch(ref_model, ref_opt, ref_bags, labels, W, We, C, j, K)
+    torch.manual_seed(77)
+    M.train(model, res, opt, dev, args)
+    got = M.train.last[0].meta_ws()[0]["loss"].cpu().numpy()
+    n_sel = M.train.last[0].n_sel.cpu().numpy()
+    if C >= 30:
+        assert n_sel.max() > 8192, "this case is here to reach the unions beyond 8,192 rows"
+    np.testing.assert_allclose(got, np.asarray(ref_losses), atol=ATOL, err_msg=name)
+    H.assert_adam_params_close(H.flat_params(model), H.flat_params(ref_model), H.flat_state(ref_opt, "exp_avg_sq"),
+                               step=len(sizes), grad_noise=1e-6, what=name)
+    # evaluation: the per-slide pooled logits and losses (main_moc.py:472-498), full bags, no mask
+    ref_model.eval()
+    ref_pooled, ref_loss = [], []
+    with torch.no_grad():
+        for x, y in zip(ref_bags, labels):
+            sr = O.slide_process(x, W, We, C, j)
+            pooled = O.pool_top(O.mix_eval(ref_model(sr["selected_feat"]), sr), [K])[1][K]
+            ref_pooled.append(pooled)
+            ref_loss.append(float(torch.nn.functional.cross_entropy(pooled, torch.as_tensor(labels[len(ref_loss)]).view(1))))
+    model.eval()
+    with torch.no_grad():
+        pooled, _, losses = M._eval_pass(res, dev, args, "eval", model=model)
+    np.testing.assert_allclose(pooled.numpy(), torch.cat(ref_pooled, 0).numpy(), atol=ATOL, err_msg=name)
+    np.testing.assert_allclose(losses, ref_loss, atol=ATOL, err_msg=name)
