@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 10
+#define MOC_ABI_VERSION 11
 
 enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
 
@@ -61,7 +61,8 @@ typedef struct moc_batch {
     int32_t        D;          /* embedding dim (512 for CONCH)                          */
     int64_t        total_rows;
     int32_t        n_slides;
-    int32_t        max_rows;   /* max rows of any slide (host value, sizes the grids)    */
+    int32_t        max_rows;   /* host bound on the rows a slide brings to the selectors (sizes grids and picks kernel
+                                  shapes): max rows of any slide, or -- tighter -- max KEPT rows (moc_host_max_kept) */
     const int64_t* row_off;    /* device [n_slides+1], first SLOT of each slide (prefix
                                   sum of the slide sizes)                                */
     const int64_t* row_off_host; /* host copy of row_off, or NULL.  With it, single-slide launches
@@ -155,6 +156,12 @@ int moc_mask_compact(const moc_batch_t* B, moc_stream_t stream);
  * torch.set_rng_state); out gets n 0/1 bytes.  Returns the number of kept rows, -1 on error.
  * Pure host code: same bits as torch.rand, no GPU involved. */
 int64_t moc_host_draw_masks(uint8_t* rng_state, int64_t state_bytes, int64_t n, uint8_t* out);
+
+/* Largest number of non-zero flags of any slide, `mask` being the host keep flags of a batch laid out by
+ * row_off_host[n_slides + 1]: a tight `max_rows` for a masked batch (the selectors only ever see the kept rows of
+ * `feat[mask]`, main_moc.py:329-331), which lets wide shapes pool inside the step kernel.  Host only; -1 on bad
+ * arguments. */
+int64_t moc_host_max_kept(const uint8_t* mask, const int64_t* row_off_host, int n_slides);
 
 /* a2 + per-row parts of a4-a6, a9: X.[W|W_ext] and the row statistics
  * (main_moc.py:336-337, :360-365; patch_selection_classifier_index.py:34, :46-48, :75).

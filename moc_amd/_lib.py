@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 MOC_F32, MOC_BF16, MOC_F16 = 0, 1, 2
 SEL_BITS = {"topk": 1, "delta_softmax": 2, "delta_diff": 4, "bottomk": 8}
@@ -57,6 +57,7 @@ SIGNATURES = {
     "moc_w1_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "moc_prepare_bank": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "moc_host_draw_masks": (C.c_int64, [_p, C.c_int64, C.c_int64, _p]),
+    "moc_host_max_kept": (C.c_int64, [_p, _p, C.c_int]),
     "moc_mask_compact": (C.c_int, [_BP, _p]),
     "moc_scores": (C.c_int, [_BP, _p, _p]),
     "moc_row_stats": (C.c_int, [_p, C.c_int64, C.c_int, C.c_int, _p, _p]),

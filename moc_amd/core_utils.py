@@ -137,6 +137,136 @@ def train_loop(epoch, model, loader, optimizer, n_classes, writer=None, loss_fn=
         writer.add_scalar("train/error", train_error, epoch)
 
 
+def train_loop_clam(epoch, model, loader, optimizer, n_classes, bag_weight, writer=None, loss_fn=None, bag_size=None):
+    """One pass of CLAM training (reference :294-370): the bag loss and the instance-level clustering loss of
+    `model(data, label=label, instance_eval=True)` mixed as bag_weight * loss + (1 - bag_weight) * instance_loss."""
+    device = _device()
+    model.train()
+    acc_logger = Accuracy_Logger(n_classes=n_classes)
+    inst_logger = Accuracy_Logger(n_classes=n_classes)
+    train_loss = train_error = train_inst_loss = 0.0
+    inst_count = 0
+    for batch_idx, (data, label) in enumerate(loader):
+        data, label = data.to(device), label.to(device)
+        logits, Y_prob, Y_hat, _, instance_dict = model(data, label=label, instance_eval=True)
+        if Y_hat.size(0) > 1:
+            acc_logger.log_batch(Y_hat.cpu(), label.cpu())
+        else:
+            acc_logger.log(Y_hat, label)
+        loss = loss_fn(logits, label)
+        loss_value = loss.item()
+        instance_loss = instance_dict["instance_loss"]
+        inst_count += 1
+        instance_loss_value = instance_loss.item()
+        train_inst_loss += instance_loss_value
+        total_loss = bag_weight * loss + (1 - bag_weight) * instance_loss
+        inst_logger.log_batch(instance_dict["inst_preds"], instance_dict["inst_labels"])
+        train_loss += loss_value
+        if (batch_idx + 1) % 20 == 0:
+            print("batch {}, loss: {:.4f}, instance_loss: {:.4f}, weighted_loss: {:.4f}, ".format(
+                batch_idx, loss_value, instance_loss_value, total_loss.item()))
+        train_error += calculate_error(Y_hat, label)
+        total_loss.backward()
+        optimizer.step()
+        optimizer.zero_grad()
+    train_loss /= len(loader)
+    train_error /= len(loader)
+    if inst_count > 0:
+        train_inst_loss /= inst_count
+        for i in range(2):
+            acc, correct, count = inst_logger.get_summary(i)
+            print("class {} clustering acc {}: correct {}/{}".format(i, acc, correct, count))
+    print("Epoch: {}, train_loss: {:.4f}, train_clustering_loss:  {:.4f}, train_error: {:.4f}".format(
+        epoch, train_loss, train_inst_loss, train_error))
+    for i in range(n_classes):
+        acc, correct, count = acc_logger.get_summary(i)
+        print("train class {}: acc {}, correct {}/{}".format(i, acc, correct, count))
+        if writer and acc is not None:
+            writer.add_scalar("train/class_{}_acc".format(i), acc, epoch)
+    if writer:
+        writer.add_scalar("train/loss", train_loss, epoch)
+        writer.add_scalar("train/error", train_error, epoch)
+        writer.add_scalar("train/clustering_loss", train_inst_loss, epoch)
+
+
+def _epoch_auc(labels, prob, n_classes):
+    """The AUC block validate / validate_clam / summary share (reference :505-519, :601-615)."""
+    if n_classes == 2:
+        return roc_auc_score(labels, prob[:, 1])
+    onehot = label_binarize(labels, classes=list(range(n_classes)))
+    per_class = []
+    for c in range(n_classes):
+        if c in labels:
+            fpr, tpr, _ = roc_curve(onehot[:, c], prob[:, c])
+            per_class.append(calc_auc(fpr, tpr))
+        else:
+            per_class.append(float("nan"))
+    return np.nanmean(np.array(per_class))
+
+
+def validate_clam(cur, epoch, model, loader, n_classes, early_stopping=None, writer=None, loss_fn=None,
+                  results_dir=None, disableAUC=False):
+    """Validation pass of CLAM with instance evaluation (reference :558-656) -> True when early stopping fires."""
+    device = _device()
+    model.eval()
+    acc_logger = Accuracy_Logger(n_classes=n_classes)
+    inst_logger = Accuracy_Logger(n_classes=n_classes)
+    val_loss = val_error = val_inst_loss = 0.0
+    inst_count = 0
+    prob = np.zeros((len(loader), n_classes))
+    labels = np.zeros(len(loader))
+    with torch.no_grad():
+        for batch_idx, (data, label) in enumerate(loader):
+            data, label = data.to(device), label.to(device)
+            logits, Y_prob, Y_hat, _, instance_dict = model(data, label=label, instance_eval=True)
+            acc_logger.log(Y_hat, label)
+            val_loss += loss_fn(logits, label).item()
+            inst_count += 1
+            val_inst_loss += instance_dict["instance_loss"].item()
+            inst_logger.log_batch(instance_dict["inst_preds"], instance_dict["inst_labels"])
+            prob[batch_idx] = Y_prob.cpu().numpy()
+            labels[batch_idx] = label.item()
+            val_error += calculate_error(Y_hat, label)
+    val_error /= len(loader)
+    val_loss /= len(loader)
+    auc = 0 if disableAUC else _epoch_auc(labels, prob, n_classes)
+    if disableAUC:
+        bacc = 0
+    else:
+        print("\nValidation Set")
+        acc_list = []
+        for i in range(n_classes):
+            acc, correct, count = acc_logger.get_summary(i)
+            print("class {}: acc {}, correct {}/{}".format(i, acc, correct, count))
+            acc_list.append(acc)
+            if writer and acc is not None:
+                writer.add_scalar("val/class_{}_acc".format(i), acc, epoch)
+        bacc = np.mean(acc_list)
+        print("balanced accuracy: ", bacc)
+    print("Val Set, val_loss: {:.4f}, val_error: {:.4f}, auc: {:.4f}, bacc: {:.4f}".format(val_loss, val_error, auc, bacc))
+    if inst_count > 0:
+        val_inst_loss /= inst_count
+        for i in range(2):
+            acc, correct, count = inst_logger.get_summary(i)
+            print("class {} clustering acc {}: correct {}/{}".format(i, acc, correct, count))
+    if writer:
+        writer.add_scalar("val/loss", val_loss, epoch)
+        writer.add_scalar("val/auc", auc, epoch)
+        writer.add_scalar("val/error", val_error, epoch)
+        writer.add_scalar("val/inst_loss", val_inst_loss, epoch)
+    if early_stopping:
+        assert results_dir
+        ckpt = os.path.join(results_dir, "s_{}_checkpoint.pt".format(cur))
+        if disableAUC:
+            early_stopping(epoch, val_loss, model, ckpt_name=ckpt)
+        else:
+            early_stopping(epoch, val_loss, model, ckpt_name=ckpt, criteria=auc)
+        if early_stopping.early_stop:
+            print("Early stopping")
+            return True
+    return False
+
+
 def validate(cur, epoch, model, loader, n_classes, early_stopping=None, writer=None, loss_fn=None, results_dir=None,
              disableAUC=False):
     """Validation pass; returns True when early stopping fires (reference :480-556)."""
@@ -231,25 +361,58 @@ def get_optim(model, args):
 
 
 def train(datasets, cur, args, pseudo=False, notsavesplit=False, require_patient_results=True, disableAUC=False):
-    """One fold of the max-instance MIL baseline (reference :105-291 for model_type 'mil'):
-    `datasets` = (train_loader, val_loader, test_loader) of (data, label) bags.  Returns
-    (results_dict, test_auc, val_auc, 1 - test_error, 1 - val_error)."""
+    """One fold (reference :105-291) for the model types on this path: 'mil' (MIL_fc / MIL_fc_mc), 'clam_sb',
+    'clam_mb' and 'abmil' (CLAM_SB without instance loss).  `datasets` = (train_loader, val_loader, test_loader) of
+    (data, label) bags.  As in the reference: CrossEntropy bag loss, get_optim, CosineAnnealingLR(optimizer, 20)
+    stepped once per epoch, EarlyStopping(patience=20, stop_epoch=40) when args.early_stopping, the CLAM loops unless
+    args.no_inst_cluster, checkpoint s_{cur}_checkpoint.pt.  Returns (results_dict, test_auc, val_auc,
+    1 - test_error, 1 - val_error).  Not here: the svm losses, tensorboard, TransMIL / ViLa / CHIEF / TITAN."""
+    from .model_clam import CLAM_MB, CLAM_SB
     from .model_mil import MIL_fc, MIL_fc_mc
-    assert getattr(args, "model_type", "mil") == "mil", "only the max-instance MIL baseline is on this path"
+    model_type = getattr(args, "model_type", "mil")
+    assert model_type in ("mil", "clam_sb", "clam_mb", "abmil"), \
+        f"model_type {model_type!r} is not on this path (mil, clam_sb, clam_mb, abmil)"
+    assert getattr(args, "bag_loss", "ce") == "ce" and getattr(args, "inst_loss", None) in (None, "ce"), \
+        "the smooth-SVM losses need the third-party `topk` package"
     os.makedirs(args.results_dir, exist_ok=True)
     train_loader, val_loader, test_loader = datasets
     loss_fn = nn.CrossEntropyLoss()
     kw = dict(dropout=getattr(args, "drop_out", False), n_classes=args.n_classes)
-    if getattr(args, "model_size", None) is not None:
+    if getattr(args, "model_size", None) is not None and model_type != "mil":
         kw["size_arg"] = args.model_size
-    model = (MIL_fc_mc if args.n_classes > 2 else MIL_fc)(**kw)
+    if model_type in ("clam_sb", "clam_mb"):
+        if getattr(args, "subtyping", False):
+            kw["subtyping"] = True
+        if getattr(args, "B", 0) > 0:
+            kw["k_sample"] = args.B
+        model = (CLAM_SB if model_type == "clam_sb" else CLAM_MB)(**kw, instance_loss_fn=nn.CrossEntropyLoss())
+    elif model_type == "abmil":
+        model = CLAM_SB(**kw, instance_loss_fn=None)
+    elif args.n_classes > 2:
+        model = MIL_fc_mc(**kw)
+    else:
+        kw["top_k"] = getattr(args, "topk", 1)
+        model = MIL_fc(**kw)
     model.relocate()
     optimizer = get_optim(model, args)
-    stopper = EarlyStopping(patience=20, stop_epoch=50, verbose=True) if getattr(args, "early_stopping", False) else None
+    scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, 20)
+    stopper = EarlyStopping(patience=20, stop_epoch=40, verbose=True) if getattr(args, "early_stopping", False) else None
+    clam_loops = model_type in ("clam_sb", "clam_mb") and not getattr(args, "no_inst_cluster", False)
     for epoch in range(args.max_epochs):
-        train_loop(epoch, model, train_loader, optimizer, args.n_classes, None, loss_fn, getattr(args, "bag_size", None))
-        if validate(cur, epoch, model, val_loader, args.n_classes, stopper, None, loss_fn, args.results_dir,
-                    disableAUC=disableAUC):
+        print("\n\nCurrent Epoch {}".format(epoch))
+        print(f"lr: {scheduler.get_last_lr()}")
+        if clam_loops:
+            train_loop_clam(epoch, model, train_loader, optimizer, args.n_classes, args.bag_weight, None, loss_fn,
+                            getattr(args, "bag_size", None))
+            scheduler.step()
+            stop = validate_clam(cur, epoch, model, val_loader, args.n_classes, stopper, None, loss_fn, args.results_dir,
+                                 disableAUC=disableAUC)
+        else:
+            train_loop(epoch, model, train_loader, optimizer, args.n_classes, None, loss_fn, getattr(args, "bag_size", None))
+            scheduler.step()
+            stop = validate(cur, epoch, model, val_loader, args.n_classes, stopper, None, loss_fn, args.results_dir,
+                            disableAUC=disableAUC)
+        if stop:
             break
     ckpt = os.path.join(args.results_dir, "s_{}_checkpoint.pt".format(cur))
     if stopper:
@@ -259,9 +422,9 @@ def train(datasets, cur, args, pseudo=False, notsavesplit=False, require_patient
     if disableAUC:
         return {}, 0, 0, 0, 0
     _, val_error, val_auc, _ = summary(model, val_loader, args.n_classes, require_patient_results=require_patient_results)
+    print("Val error: {:.4f}, ROC AUC: {:.4f}".format(val_error, val_auc))
     results, test_error, test_auc, acc_logger = summary(model, test_loader, args.n_classes,
                                                         require_patient_results=require_patient_results)
-    print("Val error: {:.4f}, ROC AUC: {:.4f}".format(val_error, val_auc))
     print("Test error: {:.4f}, ROC AUC: {:.4f}".format(test_error, test_auc))
     print("Test balanced accuracy: ", np.mean(_class_report(acc_logger, args.n_classes)))
     return results, test_auc, val_auc, 1 - test_error, 1 - val_error

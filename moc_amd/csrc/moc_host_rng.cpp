@@ -87,3 +87,23 @@ extern "C" int64_t moc_host_draw_masks(uint8_t* rng_state, int64_t state_bytes, 
     *next = (uint64_t)nx;
     return kept;
 }
+
+// The largest number of kept rows of any slide, from the keep flags the GPU is about to read: `max_rows` of the batch
+// (moc_hip.h) only has to bound the rows a slide brings to the selectors, and with a row mask that is the kept rows --
+// about half.  The bound decides kernel shapes (a 30-way union of ~7,500 kept rows pools inside the step kernel,
+// <= 8,192; bounded by the 15,000 rows of the bag it would take the separate top-K launch every step).
+extern "C" int64_t moc_host_max_kept(const uint8_t* mask, const int64_t* row_off_host, int n_slides) {
+    if (!mask || !row_off_host || n_slides < 1) {
+        moc_set_error("moc_host_max_kept: bad arguments");
+        return -1;
+    }
+    int64_t best = 0;
+    for (int b = 0; b < n_slides; ++b) {
+        const uint8_t* m = mask + row_off_host[b];
+        const int64_t n = row_off_host[b + 1] - row_off_host[b];
+        int64_t k = 0;
+        for (int64_t i = 0; i < n; ++i) k += m[i] != 0;
+        best = k > best ? k : best;
+    }
+    return best;
+}

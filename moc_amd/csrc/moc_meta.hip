@@ -1690,7 +1690,10 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
                 MOC_FAIL(MOC_ELAUNCH, "moc_fused_step: cannot raise the dynamic LDS limit to %d bytes", FS_MAX_DYN_LDS);
             wide_attr = true;
         }
-        const int external = s_bound(B) > 8192;
+        // pooling inside the kernel: every one of the 16 workgroups ranks all C classes for itself -- fine for a few
+        // ten thousand scores, not for EBRAINS-30's 30 x 7,500 (measured: 88 us against 11.4 + 28 with one workgroup per
+        // class in topk_mean_kernel first); beyond 8,192 rows it does not fit the registers at all
+        const int external = s_bound(B) > 8192 || (int64_t)B->C * s_bound(B) > 49152;
         if (external) {
             if (int rc = launch_pool(B, ws, slide, 1, s)) return rc;
             a.topk_idx = ws->topk_idx; a.topk_cnt = ws->topk_cnt;

@@ -138,6 +138,11 @@ class SlideBatch:
         self._host_mask = pinned_mask_u8
         self.c.mask = pinned_mask_u8.data_ptr()
         self.kept_rows_host = int(kept_rows)
+        # the flags are host bytes: the exact largest kept-row count of any slide is a tighter max_rows than the bag
+        # sizes (about half) -- it sizes the grids of everything after the compaction and decides kernel shapes
+        mk = int(lib().moc_host_max_kept(pinned_mask_u8.data_ptr(), C.cast(self._row_off_c, C.c_void_p), self.n_slides))
+        assert 0 <= mk <= max(self.sizes)
+        self.c.max_rows = max(1, mk)
 
     # ---- phase A ----
     def phase_a(self, bank: Bank):

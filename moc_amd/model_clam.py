@@ -7,7 +7,13 @@ gate, softmax over N, attention-weighted sum of the patch features.  That whole 
 the bag on the HIP path (moc_gated_attention_pool: fp32 MFMA projections, gate and scores in registers,
 online softmax; engine.gated_attention_pool); the layers around it (the first fc, the bag and instance
 classifiers) are plain torch GEMMs.  The backward pass re-derives the step with torch operations from
-the saved inputs (the forward keeps neither the [N, D] activations nor the softmax)."""
+the saved inputs (the forward keeps neither the [N, D] activations nor the softmax).
+
+The un-gated network (`gate=False`, Attn_Net: A = Wc tanh(Wa h + ba) + bc) runs through the same kernel with a gate
+that is exactly one: Wb = 0 and bb = 40 give sigmoid(40) = 1 - 4e-18, which IS 1.0f in fp32 (and 1 + e^-40 == 1.0f in
+the kernel's own form of the gate).  Dropout inside the attention network (p = 0.25 on the tanh / sigmoid branches) is
+active only in training mode; its masks are torch's, so in that one mode the scores are formed by torch operations
+(evaluation, and training without dropout, stay on the kernel)."""
 from __future__ import annotations
 
 import numpy as np
@@ -62,6 +68,48 @@ def gated_attention_pool(h, Wa, ba, Wb, bb, Wc, bc):
     return _GatedAttentionPool.apply(h, Wa, ba, Wb, bb, Wc, bc)
 
 
+def _pool_with_dropout(h, attn):
+    """Training mode with dropout inside the attention network (models/model_clam.py:24-25, :50-52): the masks are
+    torch's, so this one mode forms the scores with torch operations -- `attn.scores_torch` applies the module's own
+    Dropout layers exactly where the reference has them.  -> (A_raw [K, N], M [K, L])."""
+    A_raw = attn.scores_torch(h).t()
+    return A_raw, torch.softmax(A_raw, dim=1) @ h
+
+
+ONE_GATE_BIAS = 40.0      # sigmoid(40) == 1.0f: an un-gated network as a gated one (module docstring)
+
+
+class Attn_Net(nn.Module):
+    """models/model_clam.py:15-33 (attention without gating): forward(x) -> (A [N, n_classes], x).  Same parameter
+    names as the reference (`module.0`, `module.2` / `module.3` with dropout)."""
+
+    def __init__(self, L=1024, D=256, dropout=False, n_classes=1):
+        super().__init__()
+        mod = [nn.Linear(L, D), nn.Tanh()]
+        if dropout:
+            mod.append(nn.Dropout(0.25))
+        mod.append(nn.Linear(D, n_classes))
+        self.module = nn.Sequential(*mod)
+        self.dropout = dropout
+        self._one_gate = None
+
+    def operands(self):
+        lin_a, lin_c = self.module[0], self.module[-1]
+        g = self._one_gate
+        if g is None or g[0].device != lin_a.weight.device or g[0].shape != lin_a.weight.shape:
+            g = self._one_gate = (torch.zeros_like(lin_a.weight), torch.full_like(lin_a.bias, ONE_GATE_BIAS))
+        return (lin_a.weight, lin_a.bias, g[0], g[1], lin_c.weight, lin_c.bias)
+
+    def scores_torch(self, x):
+        return self.module(x)
+
+    def forward(self, x):
+        if self.dropout and self.training:
+            return self.scores_torch(x), x
+        A_raw, _ = gated_attention_pool(x, *self.operands())
+        return A_raw.t(), x
+
+
 class Attn_Net_Gated(nn.Module):
     """models/model_clam.py:41-64: forward(x) -> (A [N, n_classes], x)."""
 
@@ -79,8 +127,12 @@ class Attn_Net_Gated(nn.Module):
         return (self.attention_a[0].weight, self.attention_a[0].bias, self.attention_b[0].weight,
                 self.attention_b[0].bias, self.attention_c.weight, self.attention_c.bias)
 
+    def scores_torch(self, x):
+        return self.attention_c(self.attention_a(x).mul(self.attention_b(x)))
+
     def forward(self, x):
-        assert not (self.dropout and self.training), "dropout inside the gate is not on the HIP path (eval mode is)"
+        if self.dropout and self.training:
+            return self.scores_torch(x), x
         A_raw, _ = gated_attention_pool(x, *self.operands())
         return A_raw.t(), x
 
@@ -103,12 +155,11 @@ class CLAM_SB(nn.Module):
         assert not conch_init, "conch_init loads a checkpoint from the authors' home directory (model_clam.py:108)"
 
     def _build(self, gate, size_arg, dropout, n_heads):
-        assert gate, "only the gated attention network is on the HIP path (SURVEY.md section 8, f4)"
         size = self.size_dict[size_arg]
         fc = [nn.Linear(size[0], size[1]), nn.ReLU()]
         if dropout:
             fc.append(nn.Dropout(0.25))
-        fc.append(Attn_Net_Gated(L=size[1], D=size[2], dropout=dropout, n_classes=n_heads))
+        fc.append((Attn_Net_Gated if gate else Attn_Net)(L=size[1], D=size[2], dropout=dropout, n_classes=n_heads))
         self.attention_net = nn.Sequential(*fc)
 
     def relocate(self):
@@ -175,8 +226,10 @@ class CLAM_SB(nn.Module):
 
     def forward_single(self, h, label=None, instance_eval=False, return_features=False, attention_only=False):
         h, attn = self._features(h)
-        assert not (attn.dropout and self.training), "dropout inside the gate is not on the HIP path (eval mode is)"
-        A_raw, M = gated_attention_pool(h, *attn.operands())          # [K, N], [K, L]: the whole aggregation
+        if attn.dropout and self.training:
+            A_raw, M = _pool_with_dropout(h, attn)                    # torch's masks: the one mode off the kernel
+        else:
+            A_raw, M = gated_attention_pool(h, *attn.operands())      # [K, N], [K, L]: the whole aggregation
         if attention_only:
             return A_raw
         results = {}

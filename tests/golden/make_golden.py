@@ -426,8 +426,8 @@ def load_reference_baselines():
 
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from helpers_baselines import (BASELINE_CASES, HOOK_CASES, EARLY_SEQS, CLAM_CASES, build_case, run_case, run_clam_case,  # noqa: E402
-                               psig as _psig, randn as _randn, hook_bags, Loader)
+from helpers_baselines import (BASELINE_CASES, HOOK_CASES, EARLY_SEQS, CLAM_CASES, CLAM_HOOK_CASES, build_case, run_case,  # noqa: E402
+                               run_clam_case, run_clam_hooks, psig as _psig, randn as _randn, hook_bags, Loader)
 
 
 def gen_clam():
@@ -442,6 +442,34 @@ def gen_clam():
         for k, v in run_clam_case(ns, kind, kw, N, label, fkw, 7000 + 13 * i).items():
             arrays[f"{name}:{k}"] = v
     save("clam", **arrays)
+
+
+def gen_clam_hooks():
+    """SURVEY.md section 8 rows f3 x f4: the reference's train_loop_clam / validate_clam (utils/core_utils.py:294-370,
+    :558-656) driving the reference's CLAM_SB / CLAM_MB, three epochs with early stopping + summary."""
+    import tempfile
+    from sklearn.metrics import auc as calc_auc
+    from sklearn.metrics import roc_curve
+    from sklearn.preprocessing import label_binarize
+    base = dict(torch=torch, nn=nn, F=F, np=np, os=os)
+    util = _extract("utils/utils.py", ["initialize_weights", "calculate_error"], dict(base))
+    clam = _extract("models/model_clam.py", ["Attn_Net", "Attn_Net_Gated", "CLAM_SB", "CLAM_MB"],
+                    dict(base, initialize_weights=util["initialize_weights"]))
+
+    class _Np:                       # utils/core_utils.py:71 says `np.Inf`, an alias NumPy 2 dropped: same constant
+        Inf = np.inf
+
+        def __getattr__(self, k):
+            return getattr(np, k)
+    core = _extract("utils/core_utils.py", ["Accuracy_Logger", "EarlyStopping", "train_loop_clam", "validate_clam", "summary"],
+                    dict(base, np=_Np(), calculate_error=util["calculate_error"], roc_auc_score=roc_auc_score, roc_curve=roc_curve,
+                         calc_auc=calc_auc, label_binarize=label_binarize))
+    arrays = {"cases": np.asarray([c[0] for c in CLAM_HOOK_CASES])}
+    for tag, kind, kw, bw in CLAM_HOOK_CASES:
+        with tempfile.TemporaryDirectory() as td:
+            for k, v in run_clam_hooks(core, clam, tag, kind, kw, bw, "cpu", td).items():
+                arrays[f"{tag}:{k}"] = v
+    save("clam_hooks", **arrays)
 
 
 def gen_baselines():
@@ -517,3 +545,4 @@ if __name__ == "__main__":
     gen_summary()
     gen_baselines()
     gen_clam()
+    gen_clam_hooks()

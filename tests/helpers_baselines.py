@@ -159,7 +159,62 @@ CLAM_CASES = [
     ("mb_small", "CLAM_MB", dict(size_arg="small", n_classes=3), 257, 1, dict()),
     ("mb_conch_inst", "CLAM_MB", dict(size_arg="conch", n_classes=4, subtyping=True), 400, 3, dict(instance_eval=True, return_features=True)),
     ("mb_big", "CLAM_MB", dict(size_arg="big", n_classes=2), 129, 0, dict(instance_eval=True)),
+    # attention without gating (Attn_Net, models/model_clam.py:15-33)
+    ("sb_nogate", "CLAM_SB", dict(gate=False, size_arg="small", n_classes=2), 210, 1, dict(instance_eval=True)),
+    ("mb_nogate", "CLAM_MB", dict(gate=False, size_arg="conch", n_classes=3, subtyping=True), 190, 2, dict(instance_eval=True, return_features=True)),
+    # dropout (p = 0.25 after the first layer and inside the attention network), TRAINING mode: the masks come from
+    # the seeded CPU generator, so this case pins where the Dropout layers sit -- on the CPU only
+    ("sb_dropout_train", "CLAM_SB", dict(size_arg="small", dropout=True, n_classes=2), 150, 1, dict(instance_eval=True)),
+    ("mb_nogate_dropout_train", "CLAM_MB", dict(gate=False, size_arg="small", dropout=True, n_classes=2), 140, 0, dict()),
 ]
+CLAM_CPU_ONLY = {"sb_dropout_train", "mb_nogate_dropout_train"}     # torch's dropout masks differ between CPU and GPU generators
+
+# trainer hooks of the CLAM models (utils/core_utils.py:294-370, :558-656): tag, class, ctor kwargs, bag_weight
+CLAM_HOOK_CASES = [
+    ("hook_clam_sb", "CLAM_SB", dict(size_arg="benchmark", n_classes=2, k_sample=4), 0.7),
+    ("hook_clam_mb", "CLAM_MB", dict(size_arg="benchmark", n_classes=3, k_sample=4, subtyping=True), 0.5),
+]
+
+
+def run_clam_hooks(core, clam_ns, tag, kind, kw, bag_weight, device, tmpdir):
+    """Three epochs of train_loop_clam + validate_clam (early stopping on the AUC criterion) + summary, the same way
+    for the reference's functions (fixture generation) and for moc_amd's (tests).  `core` / `clam_ns`: namespaces or
+    dicts holding the functions / classes."""
+    import contextlib
+    import io
+    import os
+    import types
+
+    import pandas as pd
+    import torch.nn as nn
+    get = (lambda ns, k: ns[k]) if isinstance(core, dict) else (lambda ns, k: getattr(ns, k))
+    C = kw["n_classes"]
+    torch.manual_seed(91)
+    model = get(clam_ns, kind)(**kw, instance_loss_fn=nn.CrossEntropyLoss()).to(device)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, weight_decay=1e-5)
+    d = model.attention_net[0].in_features
+    tr, va = Loader(hook_bags(6500, 9, d, C)), Loader(hook_bags(6600, 9, d, C))
+    va.dataset = types.SimpleNamespace(slide_data=pd.DataFrame({"slide_id": [f"s{k}" for k in range(len(va))]}))
+    loss_fn = nn.CrossEntropyLoss()
+    with contextlib.redirect_stdout(io.StringIO()):
+        stop = get(core, "EarlyStopping")(patience=2, stop_epoch=1, verbose=True)
+        trace = []
+        for epoch in range(3):
+            get(core, "train_loop_clam")(epoch, model, tr, opt, C, bag_weight, None, loss_fn)
+            fired = get(core, "validate_clam")(0, epoch, model, va, C, stop, None, loss_fn, str(tmpdir))
+            trace.append([float(fired), stop.counter, float(stop.best_score), float(stop.val_loss_min)])
+            if fired:
+                break
+        res, err, auc, logger = get(core, "summary")(model, va, C)
+    assert os.path.exists(os.path.join(str(tmpdir), "s_0_checkpoint.pt"))
+    # the bias of the attention scores has a gradient that is zero by construction (softmax over the patches is
+    # shift invariant): under Adam it performs a random walk on rounding noise -- in the reference as here.  Its psig
+    # row is recorded but not compared.
+    noise_rows = np.asarray([i for i, (n, _) in enumerate(sorted(model.named_parameters()))
+                             if n.endswith("attention_c.bias") or (".module." in n and n.endswith("bias") and n.split(".")[-2] != "0")])
+    return dict(psig=psig(model), noise_rows=noise_rows, trace=np.asarray(trace), summary=np.asarray([err, auc]),
+                acc=np.asarray([[logger.get_summary(i)[1], logger.get_summary(i)[2]] for i in range(C)], dtype=np.float64),
+                probs=np.stack([res[f"s{k}"]["prob"].reshape(-1) for k in range(len(va))]))
 
 
 def run_clam_case(ns, kind, kw, N, label, fkw, seed, device="cpu"):

@@ -130,3 +130,36 @@ def test_clam_models_match_reference_outputs(i):
     with BO.patched():
         name, got = run_clam(i, "cpu")
     check_clam(name, got, 2e-5)
+
+
+# ---------------------------------------------------------------- rows f3 x f4: the CLAM trainer hooks
+CLAM_HOOKS = H.golden("clam_hooks")
+
+
+def check_clam_hooks(got, tag, tol=2e-5):
+    np.testing.assert_allclose(got["trace"], CLAM_HOOKS[f"{tag}:trace"], atol=tol, rtol=0, err_msg=f"{tag}: validate_clam / early-stopping trace")
+    np.testing.assert_allclose(got["summary"], CLAM_HOOKS[f"{tag}:summary"], atol=tol, rtol=0)
+    np.testing.assert_array_equal(got["acc"], CLAM_HOOKS[f"{tag}:acc"])
+    np.testing.assert_allclose(got["probs"], CLAM_HOOKS[f"{tag}:probs"], atol=tol, rtol=0)
+    keep = np.setdiff1d(np.arange(got["psig"].shape[0]), got["noise_rows"])
+    assert len(keep) >= got["psig"].shape[0] - 1
+    np.testing.assert_allclose(got["psig"][keep], CLAM_HOOKS[f"{tag}:psig"][keep], rtol=2e-5, atol=2e-6, err_msg=f"{tag}: parameters after training")
+
+
+@pytest.mark.parametrize("case", HB.CLAM_HOOK_CASES, ids=[c[0] for c in HB.CLAM_HOOK_CASES])
+def test_clam_trainer_hooks_match_reference(case, tmp_path, monkeypatch):
+    """train_loop_clam (bag loss + instance loss mixed by bag_weight), validate_clam (AUC-criterion early stopping) and
+    summary, with CLAM_SB / CLAM_MB, against what the reference's own functions and classes produced."""
+    import moc_amd.core_utils as core
+    import moc_amd.model_clam as Mc
+    monkeypatch.setattr(core, "_device", lambda: torch.device("cpu"))
+    with BO.patched():
+        got = HB.run_clam_hooks(core, Mc, *case, torch.device("cpu"), tmp_path)
+    check_clam_hooks(got, case[0])
+
+
+def test_core_utils_train_refuses_what_is_not_on_the_path(tmp_path):
+    import moc_amd.core_utils as core
+    args = types.SimpleNamespace(model_type="transmil", n_classes=2, results_dir=str(tmp_path))
+    with pytest.raises(AssertionError, match="not on this path"):
+        core.train((None, None, None), 0, args)

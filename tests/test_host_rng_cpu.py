@@ -69,3 +69,21 @@ def test_rejects_a_state_with_nothing_left():
     out = torch.empty(16, dtype=torch.uint8)
     assert lib().moc_host_draw_masks(ptr(st), st.numel(), 16, ptr(out)) < 0
     assert b"unexpected generator state" in C.cast(lib().moc_last_error(), C.c_char_p).value
+
+
+def test_max_kept_is_the_largest_per_slide_count():
+    import ctypes as C
+    import numpy as np
+    from moc_amd._lib import lib
+    rng = np.random.default_rng(3)
+    sizes = [1, 17, 4096, 15000, 9, 8193]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    mask = (rng.random(off[-1]) > 0.5).astype(np.uint8)
+    mask[off[2]:off[3]] = 1                                   # one slide keeps everything
+    got = lib().moc_host_max_kept(mask.ctypes.data, off.ctypes.data, len(sizes))
+    assert got == max(int(mask[off[b]:off[b + 1]].sum()) for b in range(len(sizes)))
+    mask[off[2]:off[3]] = 0
+    mask[off[3]:off[4]] = 0
+    got = lib().moc_host_max_kept(mask.ctypes.data, off.ctypes.data, len(sizes))
+    assert got == max(int(mask[off[b]:off[b + 1]].sum()) for b in range(len(sizes)))
+    assert lib().moc_host_max_kept(None, off.ctypes.data, 3) == -1
