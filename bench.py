@@ -43,6 +43,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TRACE = os.environ.get("MOC_BENCH_TRACE") == "1"      # host time per pass on stderr (diagnostic)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -262,12 +263,15 @@ def main():
                 nxt = lengths[i + 1] if i + 1 < len(lengths) else then
                 res.repeat_num = m if m < self.per_pass else None
                 res.next_pass_len = nxt if nxt is not None else 0      # 0: no pass follows
+                t_in = time.perf_counter()
                 if self.mode == "seq":
                     mdist.train_seq(self.model, res, self.opt, dev, args)
                 elif self.mode in ("dp_strong", "dp_weak"):
                     mdist.train_dp(self.model, res, self.opt, dev, args)
                 else:
                     M.train(self.model, res, self.opt, dev, args)
+                if TRACE:
+                    print(f"trace: pass of {m} (next {nxt}) issued in {(time.perf_counter() - t_in) * 1e6:.0f} us", file=sys.stderr)
             res.repeat_num = None
             res.next_pass_len = None
 

@@ -563,6 +563,7 @@ class SeqShardedBags(ShardedSplit):
 
 
 def _seq_plan(sh: SeqShardedBags, m: int, bank, args):
+    import ctypes
     from . import engine
     from .engine import CompactBatch, SlideBatch
     key = (m, bank.C, bank.Ce, args.topj, args.topk, tuple(sorted(args.discard_classifiers or ())))
@@ -609,6 +610,7 @@ def _seq_plan(sh: SeqShardedBags, m: int, bank, args):
         "row_lo": starts[sh.lo], "row_hi": starts[min(m, sh.hi)] if n_loc else starts[sh.lo], "rows_total": starts[m],
         "labels": torch.tensor(sh.all_labels[:m] + [0] * (per * world - m), dtype=torch.int64).to(dev),
         "all_masks": torch.empty(starts[m], dtype=torch.uint8),
+        "drawer": engine.MaskDrawer(starts[m], (ctypes.c_int64 * (m + 1))(*starts[:m + 1]), m),
     }
     return plan
 
@@ -631,17 +633,24 @@ def _seq_issue(sh, plan, turn, bank, rng_before, group, host_wait=None):
     -> generator state after the draws (None: torch drew for us)."""
     from . import engine
     st = plan["sets"][turn]
-    if st["stage_free"] is not None:
-        st["stage_free"].synchronize()
-    _, _, rng_after = engine.draw_row_masks_from(rng_before, plan["rows_total"], plan["all_masks"])
+    n_loc, cap = plan["n_loc"], plan["cap"]
+    drawn = plan["drawer"].take(rng_before)             # the whole pass's flags, usually drawn a pass ahead (helper thread)
+    if drawn is not None:
+        allm, _, _, rng_after, buf = drawn
+        mine = allm[plan["row_lo"]:plan["row_hi"]]      # this rank's rows: a view of the pinned buffer, read in place
+    else:                                               # generator layout unknown to the replay: torch draws, in line
+        if st["stage_free"] is not None:
+            st["stage_free"].synchronize()
+        _, _, rng_after = engine.draw_row_masks_from(rng_before, plan["rows_total"], plan["all_masks"])
+        buf = None
+        if n_loc:
+            st["stage"].copy_(plan["all_masks"][plan["row_lo"]:plan["row_hi"]])
+        mine = st["stage"]
     if host_wait is not None:
         host_wait.synchronize()
-    n_loc, cap = plan["n_loc"], plan["cap"]
     if n_loc:
-        mine = plan["all_masks"][plan["row_lo"]:plan["row_hi"]]
-        st["stage"].copy_(mine)
         b = st["local"]
-        b.use_host_mask(st["stage"], int(mine.sum()))
+        b.use_host_mask(mine, int(mine.sum()))
         b.phase_a(bank)
         engine.pack_selected(b, 0, n_loc, cap, st["send_feat"], st["send_cand"])
         st["send_nsel"][:n_loc].copy_(b.n_sel)
@@ -657,7 +666,10 @@ def _seq_issue(sh, plan, turn, bank, rng_before, group, host_wait=None):
     cb.blocks_to_columns()
     ev = torch.cuda.Event()
     ev.record()
-    st["stage_free"] = ev
+    if buf is not None:
+        plan["drawer"].attach(buf, ev)
+    else:
+        st["stage_free"] = ev
     return rng_after
 
 

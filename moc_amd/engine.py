@@ -129,7 +129,7 @@ class SlideBatch:
         self.c.mask = ptr(self.mask)
         self.kept_rows_host = int(kept_rows)
 
-    def use_host_mask(self, pinned_mask_u8: torch.Tensor, kept_rows: int):
+    def use_host_mask(self, pinned_mask_u8: torch.Tensor, kept_rows: int, max_kept: int | None = None):
         """Keep flags read by the compaction kernel straight from PINNED host memory (device-mapped by
         hipHostMalloc): no copy command at all.  Measured on the GPU box: the 480 KB asynchronous upload it
         replaces blocked the issuing thread for ~7 ms once every few dozen epochs (scripts/diag_stall.py).
@@ -140,7 +140,8 @@ class SlideBatch:
         self.kept_rows_host = int(kept_rows)
         # the flags are host bytes: the exact largest kept-row count of any slide is a tighter max_rows than the bag
         # sizes (about half) -- it sizes the grids of everything after the compaction and decides kernel shapes
-        mk = int(lib().moc_host_max_kept(pinned_mask_u8.data_ptr(), C.cast(self._row_off_c, C.c_void_p), self.n_slides))
+        mk = max_kept if max_kept is not None else \
+            int(lib().moc_host_max_kept(pinned_mask_u8.data_ptr(), C.cast(self._row_off_c, C.c_void_p), self.n_slides))
         assert 0 <= mk <= max(self.sizes)
         self.c.max_rows = max(1, mk)
 
@@ -317,6 +318,92 @@ def draw_row_masks_from(rng_state: torch.Tensor, total: int, out: torch.Tensor):
     m = torch.rand(total) > 0.5
     out.copy_(m)
     return out, int(m.sum()), None
+
+
+class MaskDrawer:
+    """The keep flags of a pass, drawn one pass AHEAD on a helper thread (the reference has a DataLoader worker process
+    beside its main thread; here the second host thread replays torch's mt19937: moc_host_draw_masks releases the GIL).
+
+    The stream is sequential, so the flags of the pass after next follow from the generator state the last draw left:
+    as soon as a draw for (state S, row layout L) is handed out, the draw for (S', L) starts in the background into a
+    spare pinned buffer.  `take(S', L)` then returns it at once; any other request (someone else drew from the
+    generator, another pass length) discards the speculation and draws in line -- the bits are always the ones
+    `torch.rand(N) > 0.5` would give from the requested state.  Buffers are pinned host memory read in place by the
+    compaction kernel: one is handed out again only after the event the caller attached to it has completed."""
+
+    def __init__(self, total: int, row_off_c, n_slides: int, n_buffers: int = 4, pinned: bool = True):
+        from concurrent.futures import ThreadPoolExecutor
+        self.total, self.row_off_c, self.n_slides = int(total), row_off_c, int(n_slides)
+        self.bufs = [torch.empty(self.total, dtype=torch.uint8) for _ in range(n_buffers)]
+        if pinned:                                # (False: the CPU tests of the draw-ahead logic)
+            self.bufs = [b.pin_memory() for b in self.bufs]
+        self.busy = [None] * n_buffers            # event after the phase A that reads buffer i (None: free)
+        self.pool = ThreadPoolExecutor(1)
+        self.ahead = None                         # (state_before, buffer index, future)
+
+    def _draw(self, state_before: torch.Tensor, i: int):
+        st = state_before.clone()
+        kept = lib().moc_host_draw_masks(ptr(st), st.numel(), self.total, ptr(self.bufs[i]))
+        if kept < 0:
+            return None
+        mk = lib().moc_host_max_kept(self.bufs[i].data_ptr(), C.cast(self.row_off_c, C.c_void_p), self.n_slides)
+        return int(kept), int(mk), st
+
+    def _free_buffer(self, exclude=()):
+        for i, ev in enumerate(self.busy):
+            if i in exclude:
+                continue
+            if ev is None or ev.query():
+                self.busy[i] = None
+                return i
+        for i, ev in enumerate(self.busy):        # none free: wait for the oldest the caller is done with
+            if i not in exclude:
+                ev.synchronize()
+                self.busy[i] = None
+                return i
+        raise AssertionError("MaskDrawer: no buffer")
+
+    def take(self, state_before: torch.Tensor):
+        """-> (pinned flags, kept rows, max kept rows of a slide, generator state after, buffer index) or None when
+        the generator state is not the layout the replay knows (the caller lets torch draw)."""
+        if torch.get_default_dtype() != torch.float32:
+            return None
+        got = None
+        if self.ahead is not None:
+            st0, i, fut = self.ahead
+            self.ahead = None
+            res = fut.result()
+            if res is not None and torch.equal(st0, state_before):
+                got = (i, res)
+            # (a discarded speculation leaves buffer i free: nothing on the GPU reads it)
+        if got is None:
+            i = self._free_buffer()
+            res = self._draw(state_before, i)
+            if res is None:
+                return None
+            got = (i, res)
+        i, (kept, mk, st_after) = got
+        # the flags of the pass after this one, in the background
+        j = self._free_buffer(exclude=(i,))
+        self.ahead = (st_after, j, self.pool.submit(self._draw, st_after, j))
+        return self.bufs[i], kept, mk, st_after, i
+
+    def prefetch(self, state_before: torch.Tensor):
+        """Start drawing the flags that follow `state_before` now (no-op when that is what is being drawn already):
+        for a caller that learns early which pass comes next -- the draw then runs beside its kernel launches."""
+        if torch.get_default_dtype() != torch.float32:
+            return
+        if self.ahead is not None:
+            if torch.equal(self.ahead[0], state_before):
+                return
+            self.ahead[2].result()                # let the stale draw finish: its buffer is free again
+            self.ahead = None
+        j = self._free_buffer()
+        self.ahead = (state_before.clone(), j, self.pool.submit(self._draw, state_before, j))
+
+    def attach(self, i: int, event):
+        """`event` completes when the GPU work that reads buffer i has run."""
+        self.busy[i] = event
 
 
 def train_use_bits(discard) -> int:

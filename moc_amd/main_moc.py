@@ -150,7 +150,8 @@ class ResidentBags:
             batches = [SlideBatch(self.X, sizes, C_, Ce, topj, topk, discard, mask=torch.ones(T, dtype=torch.uint8),
                                   x_starts=[self.starts[k] for k in order]) for _ in range(2)]
             lab = torch.tensor([self.labels[k] for k in order], dtype=torch.int64).to(self.X.device)
-            stage = [torch.empty(T, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            stage = [torch.empty(T, dtype=torch.uint8).pin_memory() for _ in range(2)]     # (only when torch itself must draw)
+            drawer = engine.MaskDrawer(T, batches[0]._row_off_c, len(sizes))
             side = torch.cuda.Stream(device=self.X.device)
             # the side stream reads X and writes the work arrays: tell the caching allocator, so that memory freed
             # while a pass-ahead phase A is still in flight is not handed to someone else under it
@@ -160,7 +161,7 @@ class ResidentBags:
                     if t is not None:
                         t.record_stream(side)
             plan = self._plans[key] = {"batch": batches[0], "batches": batches, "labels": lab, "stage": stage,
-                                       "stage_free": [None, None], "turn": 0, "ahead": None, "side": side}
+                                       "stage_free": [None, None], "turn": 0, "ahead": None, "side": side, "drawer": drawer}
         return plan
 
     def eval_plan(self, C_, Ce, topj, topk, discard):
@@ -270,6 +271,8 @@ def slide_process(feat, zeroshot_weights, zeroshot_weights_ext,
 
 
 PREFETCH_PHASE_A = os.environ.get("MOC_PREFETCH_PHASE_A", "1") != "0"
+MASK_AHEAD = os.environ.get("MOC_MASK_AHEAD", "1") != "0"   # keep flags drawn a pass ahead on a helper thread (engine.MaskDrawer)
+_TRACE = os.environ.get("MOC_BENCH_TRACE") == "1"          # host time of train()'s four parts on stderr (diagnostic)
 
 
 def _issue_phase_a(plan, turn, bank, rng_before, host_wait=None):
@@ -277,16 +280,24 @@ def _issue_phase_a(plan, turn, bank, rng_before, host_wait=None):
     upload them and run phase A into work-array set `turn` on the CURRENT stream.
     -> generator state after the draws (None: the state's layout is unknown, torch drew and advanced itself)."""
     batch = plan["batches"][turn]
-    if plan["stage_free"][turn] is not None:
-        plan["stage_free"][turn].synchronize()          # the phase A that read that pinned buffer has run
-    stage, kept, rng_after = engine.draw_row_masks_from(rng_before, batch.total, plan["stage"][turn])
+    drawn = plan["drawer"].take(rng_before) if MASK_AHEAD else None    # usually ready: drawn a pass ahead on the helper thread
+    if drawn is not None:
+        stage, kept, max_kept, rng_after, buf = drawn
+    else:                                               # generator layout unknown to the replay: torch draws, in line
+        if plan["stage_free"][turn] is not None:
+            plan["stage_free"][turn].synchronize()      # the phase A that read that pinned buffer has run
+        stage, kept, rng_after = engine.draw_row_masks_from(rng_before, batch.total, plan["stage"][turn])
+        max_kept, buf = None, None
     if host_wait is not None:
         host_wait.synchronize()                         # (after the draw: the host works while it would wait)
-    batch.use_host_mask(stage, kept)                    # read in place by the compaction kernel: no upload
+    batch.use_host_mask(stage, kept, max_kept)          # read in place by the compaction kernel: no upload
     batch.phase_a(plan["bank"])
     ev = torch.cuda.Event()
     ev.record()
-    plan["stage_free"][turn] = ev                       # ... so the buffer is free again when phase A has run
+    if buf is not None:
+        plan["drawer"].attach(buf, ev)                  # ... so the buffer is free again when phase A has run
+    else:
+        plan["stage_free"][turn] = ev
     return rng_after
 
 
@@ -319,7 +330,28 @@ def _resident_pass_setup(res, device, args):
         if after is not None:
             torch.set_rng_state(after)
     plan["batch"] = plan["batches"][plan["turn"]]
+    if PREFETCH_PHASE_A and not res.loader_seed_draw:
+        # the generator now stands where the NEXT pass's draws start: let the helper thread draw them beside this
+        # pass's kernel launches (a no-op when it is already drawing exactly that)
+        nplan = _next_plan(res, plan, bank, args)
+        if nplan is not None and MASK_AHEAD:
+            nplan["drawer"].prefetch(torch.get_rng_state())
     return plan["batch"], lab, bank
+
+
+def _next_plan(res, plan, bank, args):
+    """The plan of the pass that follows this one: the same visits (the reference's epoch loop), or what the caller
+    announced in `res.next_pass_len` (0: no pass follows -> None)."""
+    hint = getattr(res, "next_pass_len", None)
+    if hint == 0:
+        return None
+    if hint is None or hint == len(res):
+        return plan
+    keep, res.repeat_num = res.repeat_num, (hint if hint != res.real_len() else None)
+    try:
+        return res.train_plan(bank.C, bank.Ce, args.topj, args.topk, args.discard_classifiers)
+    finally:
+        res.repeat_num = keep
 
 
 def resident_pass_done(res, device, args):
@@ -339,19 +371,12 @@ def resident_pass_done(res, device, args):
     mark = torch.cuda.Event()
     mark.record(main)
     plan.setdefault("steps_done", [None, None])[plan["turn"]] = mark
-    hint = getattr(res, "next_pass_len", None)
-    if hint == 0:
+    nplan = _next_plan(res, plan, bank, args)
+    if nplan is None:
         return
-    nplan = plan
-    if hint is not None and hint != len(res):
-        keep, res.repeat_num = res.repeat_num, (hint if hint != res.real_len() else None)
-        try:
-            nplan = res.train_plan(bank.C, bank.Ce, args.topj, args.topk, args.discard_classifiers)
-        finally:
-            res.repeat_num = keep
-        if nplan.get("ahead") is not None:                # (an unadopted speculation of that plan still owns a set)
-            nplan["ahead"]["done"].synchronize()
-            nplan["ahead"] = None
+    if nplan is not plan and nplan.get("ahead") is not None:     # (an unadopted speculation of that plan still owns a set)
+        nplan["ahead"]["done"].synchronize()
+        nplan["ahead"] = None
     nplan["bank"] = bank
     other, side = 1 - nplan["turn"], nplan["side"]
     before = torch.get_rng_state()
@@ -374,10 +399,24 @@ def train(model, train_loader, optimizer, device, args):
     use = engine.train_use_bits(args.discard_classifiers)
     if isinstance(train_loader, ResidentBags):
         _loader_seed_draw(train_loader)
+        if _TRACE:
+            import time
+            t0 = time.perf_counter()
         batch, lab, bank = _resident_pass_setup(train_loader, device, args)      # phase A issued (or adopted)
+        if _TRACE:
+            t1 = time.perf_counter()
         meta = MetaState(model, optimizer)
+        if _TRACE:
+            t2 = time.perf_counter()
         engine.train_steps(batch, meta, lab, 0, batch.n_slides, use)
+        if _TRACE:
+            t3 = time.perf_counter()
         resident_pass_done(train_loader, device, args)
+        if _TRACE:
+            t4 = time.perf_counter()
+            import sys
+            print(f"trace:   setup {(t1 - t0) * 1e6:.0f}  meta {(t2 - t1) * 1e6:.0f}  launches {(t3 - t2) * 1e6:.0f}  pass_done {(t4 - t3) * 1e6:.0f} us",
+                  file=sys.stderr)
         train.last = (batch, lab)
         return
     X, sizes, x_starts, labels = _collect(train_loader, device, args)

@@ -87,3 +87,52 @@ def test_max_kept_is_the_largest_per_slide_count():
     got = lib().moc_host_max_kept(mask.ctypes.data, off.ctypes.data, len(sizes))
     assert got == max(int(mask[off[b]:off[b + 1]].sum()) for b in range(len(sizes)))
     assert lib().moc_host_max_kept(None, off.ctypes.data, 3) == -1
+
+
+def test_mask_drawer_hands_out_torchs_bits_whether_or_not_its_speculation_holds():
+    """engine.MaskDrawer draws the NEXT pass's flags on a helper thread; whatever happens to the generator in between,
+    what it hands out for a state are the bits torch.rand(N) > 0.5 gives from that state."""
+    import ctypes as C
+    sizes = [700, 1300, 5, 2048]
+    off = [0]
+    for n in sizes:
+        off.append(off[-1] + n)
+    row_off_c = (C.c_int64 * len(off))(*off)
+    d = engine.MaskDrawer(off[-1], row_off_c, len(sizes), pinned=False)
+
+    class Ev:                       # stands in for the CUDA event attached to a buffer
+        def __init__(self):
+            self.done = False
+
+        def query(self):
+            return self.done
+
+        def synchronize(self):
+            self.done = True
+
+    def reference(state):
+        torch.set_rng_state(state)
+        m = torch.cat([torch.rand(n) > 0.5 for n in sizes])
+        return m, torch.get_rng_state()
+
+    torch.manual_seed(2024)
+    state = torch.get_rng_state()
+    used = []
+    for step in range(12):
+        if step in (4, 9):                                   # somebody else draws: the speculation must be dropped
+            torch.set_rng_state(state)
+            torch.rand(3)
+            state = torch.get_rng_state()
+        buf, kept, mk, after, i = d.take(state)
+        ref, ref_after = reference(state)
+        assert torch.equal(buf.bool(), ref) and kept == int(ref.sum())
+        assert mk == max(int(ref[off[b]:off[b + 1]].sum()) for b in range(len(sizes)))
+        assert torch.equal(after, ref_after)
+        ev = Ev()
+        d.attach(i, ev)
+        used.append((i, ev, buf.clone(), buf))
+        if len(used) > 2:                                    # the GPU finishes with a buffer two passes later
+            used[-3][1].done = True
+        for j, e, snap, b in used[-2:]:
+            assert torch.equal(snap, b), "a buffer still in use was overwritten"
+        state = after
