@@ -1,0 +1,51 @@
+"""bench.py as the driver runs it, on the GPU box: the one-GPU line carries what the contract asks for (value over
+exactly --steps steps, a steady_state block, roofline measured live, traffic null or matched), and `--gpus 2` starts
+its own ranks -- rehearsed with both ranks on the one card (MOC_BENCH_ONE_DEVICE=1, gloo): the exact-sequential mode
+is `value`, minibatch data parallelism an extra block, and the ranks end with bit-identical parameters (bench.py
+asserts that itself)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, env=None, timeout=600):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout, env=e)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must carry ONE JSON line, got {len(lines)}"
+    return json.loads(lines[0])
+
+
+def test_one_gpu_line(gpu_device):
+    d = _bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2", "--steady-epochs", "10")
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "meta-steps/s"
+    assert d["value"] > 5000 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1.0
+    assert d["config"]["workload"].startswith("NSCLC 2-way 16-shot") and d["dtype"] == "f32" and d["vs_baseline"] is None
+    ss = d["steady_state"]
+    assert ss["epochs"] == 10 and ss["steps"] == 320 and ss["value"] > d["value"] * 0.8
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["kernel"] == "scores_stream_kernel<16, true, 1, false>" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.2 < roof["frac"] < 1.0
+    assert roof["traffic"] is None or "traffic_source" in roof       # a 20-slide launch matches no committed capture
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 10 and cpu["cores"] >= 1 and "sample" in cpu
+    assert d["eval_slides_per_sec"] > 10000
+
+
+def test_gpus_2_starts_its_own_ranks_and_reports_the_exact_sequential_mode(gpu_device):
+    d = _bench("--gpus", "2", "--steps", "32", "--warmup", "32", "--no-eval", "--steady-epochs", "2",
+               env={"MOC_BENCH_ONE_DEVICE": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 100
+    assert d["config"]["parallelism"].startswith("seq2: exact-sequential")
+    assert "rehearsal" in d
+    mb = d["minibatch_dp"]
+    assert mb["dp_strong"]["value"] > 100 and mb["dp_weak"]["value"] > 100 and mb["dp_strong"]["exchange"] in ("p2p", "collective")
+    assert "NOT within" in mb["note"]
