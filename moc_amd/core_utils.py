@@ -362,16 +362,16 @@ def get_optim(model, args):
 
 def train(datasets, cur, args, pseudo=False, notsavesplit=False, require_patient_results=True, disableAUC=False):
     """One fold (reference :105-291) for the model types on this path: 'mil' (MIL_fc / MIL_fc_mc), 'clam_sb',
-    'clam_mb' and 'abmil' (CLAM_SB without instance loss).  `datasets` = (train_loader, val_loader, test_loader) of
+    'clam_mb', 'abmil' (CLAM_SB without instance loss) and 'transmil'.  `datasets` = (train_loader, val_loader, test_loader) of
     (data, label) bags.  As in the reference: CrossEntropy bag loss, get_optim, CosineAnnealingLR(optimizer, 20)
     stepped once per epoch, EarlyStopping(patience=20, stop_epoch=40) when args.early_stopping, the CLAM loops unless
     args.no_inst_cluster, checkpoint s_{cur}_checkpoint.pt.  Returns (results_dict, test_auc, val_auc,
-    1 - test_error, 1 - val_error).  Not here: the svm losses, tensorboard, TransMIL / ViLa / CHIEF / TITAN."""
+    1 - test_error, 1 - val_error).  Not here: the svm losses, tensorboard, ViLa / CHIEF / TITAN."""
     from .model_clam import CLAM_MB, CLAM_SB
-    from .model_mil import MIL_fc, MIL_fc_mc
+    from .model_mil import MIL_fc, MIL_fc_mc, TransMIL
     model_type = getattr(args, "model_type", "mil")
-    assert model_type in ("mil", "clam_sb", "clam_mb", "abmil"), \
-        f"model_type {model_type!r} is not on this path (mil, clam_sb, clam_mb, abmil)"
+    assert model_type in ("mil", "clam_sb", "clam_mb", "abmil", "transmil"), \
+        f"model_type {model_type!r} is not on this path (mil, clam_sb, clam_mb, abmil, transmil)"
     assert getattr(args, "bag_loss", "ce") == "ce" and getattr(args, "inst_loss", None) in (None, "ce"), \
         "the smooth-SVM losses need the third-party `topk` package"
     os.makedirs(args.results_dir, exist_ok=True)
@@ -388,12 +388,17 @@ def train(datasets, cur, args, pseudo=False, notsavesplit=False, require_patient
         model = (CLAM_SB if model_type == "clam_sb" else CLAM_MB)(**kw, instance_loss_fn=nn.CrossEntropyLoss())
     elif model_type == "abmil":
         model = CLAM_SB(**kw, instance_loss_fn=None)
+    elif model_type == "transmil":
+        model = TransMIL(**kw)
     elif args.n_classes > 2:
         model = MIL_fc_mc(**kw)
     else:
         kw["top_k"] = getattr(args, "topk", 1)
         model = MIL_fc(**kw)
-    model.relocate()
+    if hasattr(model, "relocate"):
+        model.relocate()
+    else:
+        model = model.to(_device())
     optimizer = get_optim(model, args)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, 20)
     stopper = EarlyStopping(patience=20, stop_epoch=40, verbose=True) if getattr(args, "early_stopping", False) else None

@@ -3,9 +3,12 @@ row f3; reference models/model_mil.py).  forward(h) -> (top_instance logits [1, 
 Y_hat, y_probs [N, C], results_dict).  The per-instance classifier is torch (a plain library GEMM);
 picking the top instance over the N patches runs on the HIP path (pool_autograd) and autograd flows
 through the picked row only, as in the reference.  Parameter names match (`classifier.{0,2}` /
-`fc.0`, `classifiers.{c}`), so reference checkpoints load."""
+`fc.0`, `classifiers.{c}`), so reference checkpoints load.  TransMIL (plain torch + the restated Nystrom attention of
+moc_amd/nystrom.py; parity unpinned: the reference's own class cannot be built without the absent third-party
+package) keeps the contract (logits, Y_prob, Y_hat, None, None)."""
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -92,20 +95,78 @@ class MIL_fc_mc(nn.Module):
         return top_instance, Y_prob, Y_hat, y_probs, results
 
 
-class TransMIL(nn.Module):
-    """models/model_mil.py:142-273: forward(data) -> (logits, Y_prob, Y_hat, None, None).  Its layers are
-    Nystrom attention from the third-party `nystrom_attention` package, which neither this image nor
-    the reference tree holds (the reference's own import of it fails here); the contract is recorded
-    and construction fails loudly rather than substituting a different attention."""
+class TransLayer(nn.Module):
+    """models/model_mil.py:105-122."""
 
-    def __init__(self, n_classes, *args, **kwargs):
+    def __init__(self, norm_layer=nn.LayerNorm, dim=512):
         super().__init__()
-        try:
-            import nystrom_attention  # noqa: F401
-        except ImportError as e:
-            raise ImportError("TransMIL needs the `nystrom_attention` package (absent here; "
-                              "reference: models/model_mil.py:6)") from e
-        raise NotImplementedError("TransMIL is outside the MOC hot path (SURVEY.md section 8, f3: signature only)")
+        from .nystrom import NystromAttention
+        self.norm = norm_layer(dim)
+        self.attn = NystromAttention(dim=dim, dim_head=dim // 8, heads=8, num_landmarks=dim // 2, pinv_iterations=6,
+                                     residual=True, dropout=0.1)
 
-    def forward(self, data, **kwargs):  # pragma: no cover
-        raise NotImplementedError
+    def forward(self, x):
+        return x + self.attn(self.norm(x))
+
+
+class PPEG(nn.Module):
+    """models/model_mil.py:125-139: depth-wise 7 / 5 / 3 convolutions over the patch tokens laid out as a square."""
+
+    def __init__(self, dim=512):
+        super().__init__()
+        self.proj = nn.Conv2d(dim, dim, 7, 1, 7 // 2, groups=dim)
+        self.proj1 = nn.Conv2d(dim, dim, 5, 1, 5 // 2, groups=dim)
+        self.proj2 = nn.Conv2d(dim, dim, 3, 1, 3 // 2, groups=dim)
+
+    def forward(self, x, H, W):
+        B, _, C = x.shape
+        cls_token, feat_token = x[:, 0], x[:, 1:]
+        cnn_feat = feat_token.transpose(1, 2).view(B, C, H, W)
+        x = self.proj(cnn_feat) + cnn_feat + self.proj1(cnn_feat) + self.proj2(cnn_feat)
+        x = x.flatten(2).transpose(1, 2)
+        return torch.cat((cls_token.unsqueeze(1), x), dim=1)
+
+
+class TransMIL(nn.Module):
+    """models/model_mil.py:142-273: forward(data) -> (logits [B, C], Y_prob, Y_hat, None, None), same modules and
+    parameter names (`pos_layer`, `_fc1`, `cls_token`, `layer1`, `layer2`, `norm`, `_fc2`).  Its attention is the
+    third-party `nystrom_attention` package, absent here AND in the reference tree (the reference's own import fails in
+    this image): the layer is restated in moc_amd/nystrom.py from the published algorithm, and since no reference
+    output can be produced, **parity of this class is unpinned** (checked: shapes, the 5-tuple, the padding rule, the
+    attention's exact-softmax limit; not checked: a reference number).  Plain torch: a signature shim, row f3."""
+
+    size_dict = {"small": 1024, "big": 1024, "benchmark": 384, "conch": 512, "gigapath": 1536, "virchow": 2560}
+
+    def __init__(self, n_classes, size_arg="small", **kwargs):
+        super().__init__()
+        size = self.size_dict[size_arg]
+        self.pos_layer = PPEG(dim=512)
+        self._fc1 = nn.Sequential(nn.Linear(size, 512), nn.ReLU())
+        self.cls_token = nn.Parameter(torch.randn(1, 1, 512))
+        self.n_classes = n_classes
+        self.layer1 = TransLayer(dim=512)
+        self.layer2 = TransLayer(dim=512)
+        self.norm = nn.LayerNorm(512)
+        self._fc2 = nn.Linear(512, self.n_classes)
+
+    def _tokens(self, data):
+        """fc1, wrap-around padding to a square, class token, layer 1, PPEG, layer 2 (:236-266)."""
+        if len(data.shape) == 2:
+            data = data.unsqueeze(0)
+        h = self._fc1(data.float())                                       # [B, n, 512]
+        H = h.shape[1]
+        side = int(np.ceil(np.sqrt(H)))
+        h = torch.cat([h, h[:, :side * side - H, :]], dim=1)              # pad with the first rows again
+        h = torch.cat((self.cls_token.expand(h.shape[0], -1, -1).to(h.device), h), dim=1)
+        h = self.layer1(h)
+        h = self.pos_layer(h, side, side)
+        return self.layer2(h), data.shape[1]
+
+    def forward_patch_level(self, data):
+        h, n = self._tokens(data)
+        return self._fc2(h).squeeze(0)[1:n + 1]                           # [n, n_classes], no final norm (:198-200)
+
+    def forward(self, data, **kwargs):
+        h, _ = self._tokens(data)
+        logits = self._fc2(self.norm(h)[:, 0])                            # [B, n_classes]
+        return logits, F.softmax(logits, dim=1), torch.argmax(logits, dim=1), None, None

@@ -131,3 +131,24 @@ def test_core_utils_train_drives_clam_end_to_end(gpu_device, tmp_path):
     res, test_auc, val_auc, test_acc, val_acc = core.train(loaders, 0, args)
     assert (tmp_path / "s_0_checkpoint.pt").exists() and len(res) == 6
     assert 0.0 <= test_auc <= 1.0 and 0.0 <= val_auc <= 1.0 and 0.0 <= test_acc <= 1.0
+
+
+def test_core_utils_train_drives_transmil(gpu_device, tmp_path):
+    """model_type 'transmil' through core_utils.train (train_loop / validate / summary) on the GPU: the class keeps
+    the reference's contract; its Nystrom attention is the restatement of moc_amd/nystrom.py (parity unpinned)."""
+    import types
+    import pandas as pd
+    import moc_amd.core_utils as core
+    C, d = 2, 512
+    loaders = []
+    for s0 in (8400, 8500, 8600):
+        ld = HB.Loader([(b.to("cuda:0"), y) for b, y in HB.hook_bags(s0, 5, d, C)])
+        ld.dataset = types.SimpleNamespace(slide_data=pd.DataFrame({"slide_id": [f"s{k}" for k in range(len(ld))]}))
+        loaders.append(ld)
+    args = types.SimpleNamespace(model_type="transmil", n_classes=C, model_size="conch", drop_out=False, opt="adam", lr=2e-4,
+                                 reg=1e-5, max_epochs=2, early_stopping=False, results_dir=str(tmp_path))
+    torch.manual_seed(6)
+    res, test_auc, val_auc, test_acc, val_acc = core.train(loaders, 0, args)
+    assert (tmp_path / "s_0_checkpoint.pt").exists() and len(res) == 5 and 0.0 <= test_auc <= 1.0
+    state = torch.load(tmp_path / "s_0_checkpoint.pt", map_location="cpu")
+    assert "layer1.attn.to_qkv.weight" in state and "pos_layer.proj.weight" in state
