@@ -399,7 +399,7 @@ def main():
         if nt <= (3 if esz == 2 else 4):
             kname = f"scores_stream_kernel<{16 if (D * esz) % 1024 == 0 else 8}, {half}, {nt}, {f16}>"
         elif esz == 2 and nt <= 8 and D % 64 == 0:
-            kname = f"scores_wide_kernel<{nt}, {f16}>"
+            kname = f"scores_wide_ring_kernel<{nt}, {f16}>" if nt <= 5 else f"scores_wide_kernel<{nt}, {f16}>"
         else:
             kname = f"scores_kernel<{512 if D % 512 == 0 else 256}, {half}, {f16}>"
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

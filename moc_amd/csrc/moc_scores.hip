@@ -675,6 +675,145 @@ __global__ __launch_bounds__(256, (NT <= 6 ? 2 : 1)) void scores_wide_kernel(Sco
     }
 }
 
+// ---- wide banks, 4..5 n-tiles: the K-split walk with TWO chunks in flight behind the one in use ---------------------
+// The double-buffered kernel above waits, once per 32-column chunk, for a DMA it issued one chunk (~1,000 cycles of
+// MFMAs) earlier; two workgroups per CU cover for each other (3.2 TB/s with nothing stored, against 10 TB/s of MFMA
+// rate).  Measured +5 % over it at 5 n-tiles (2.94 against 2.81 TB/s on 64 x 50 k x 1024 fp16, 3.07 against 2.86
+// unmasked): what is left is not the look-ahead -- every row arrives as 32 separate 64-byte pieces, one per chunk,
+// and HBM serves such pieces far below its streaming rate.  Here
+//   * the image slices go through a ring of THREE LDS slots (16 KiB each at 5 n-tiles), loaded by LDS-DMA;
+//   * the A fragments do not touch LDS at all: every wave loads its own four row tiles' 16-B pieces straight into a
+//     ring of three register sets (asm loads the compiler does not see), two chunks ahead (a fourth set spills);
+//   * both kinds of request are issued together, P per wave and chunk, so ONE in-order counter covers them:
+//       iteration c:  s_waitcnt vmcnt(P)   -- chunk c (image pieces of this wave + its A fragments) has landed
+//                     raw s_barrier         -- ... everybody's image pieces too; all waves are done reading slot c-1
+//                     request chunk c+2 (image -> the slot chunk c-1 just left, A -> register set (c+2) mod 3)
+//                     the MFMAs of chunk c
+//   * 48 KiB of LDS and <= 256 registers: two workgroups per CU, as before -- 128 KiB in flight per CU instead of 62.
+// No __syncthreads() in the loop (its fence would wait vmcnt(0) and drain the ring); every LDS read is hand-issued.
+template <int NT, bool F16>
+__global__ __launch_bounds__(256, 2) void scores_wide_ring_kernel(ScoresArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RING = 3;
+    constexpr int B_PIECES = NT * 3, B_PER_WAVE = (B_PIECES + 3) / 4;      // image pieces of one chunk, dealt to 4 waves
+    constexpr int P = B_PER_WAVE + WD_R;                                    // requests per wave per chunk (uniform)
+    constexpr int SLOT = B_PER_WAVE * 4 * 1024;                             // (padded to a whole round of the deal)
+    constexpr int LDT = NT * 16 + 1;
+    float* tile = reinterpret_cast<float*>(smem) + (threadIdx.x >> 6) * 16 * LDT;      // (the epilogue's tiles reuse the ring)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int64_t base = a.row_off[b];
+    const int64_t xbase = a.x_off ? a.x_off[b] : base;
+    const int n = (int)(a.row_off[b + 1] - base);
+    const int nk = a.kept ? a.n_kept[b] : n;
+    const int wg_row0 = blockIdx.x * (4 * WD_R * 16);
+    if (wg_row0 >= nk) return;
+    const int64_t row_bytes = (int64_t)a.D * 2;
+    const int nchunk = a.D / 32;                                    // a multiple of 8 (D is a multiple of 256)
+    const int img_bytes = nchunk * 3 * 1024;                        // one n-tile of the image
+
+    const unsigned char* rp[WD_R];                                  // this lane's row in each of the wave's row tiles
+#pragma unroll
+    for (int r = 0; r < WD_R; ++r) {
+        int slot = wg_row0 + (wave * WD_R + r) * 16 + (lane & 15);
+        slot = slot < nk ? slot : nk - 1;                           // clamp: loads stay in bounds
+        const int row = a.kept ? a.kept[base + slot] : slot;
+        rp[r] = a.X + (xbase + row) * row_bytes + (lane >> 4) * 16;
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto issue_image = [&](int c) {
+        unsigned char* dst = smem + (c % RING) * SLOT;
+        // piece = [nt][term]; slot i*4 + wave of the padded deal -- a slot past the last piece re-loads piece 0 (into its
+        // own padding slot), so that EVERY wave issues exactly B_PER_WAVE image DMAs per chunk
+#pragma unroll
+        for (int i = 0; i < B_PER_WAVE; ++i) {
+            const int sl = i * 4 + wave;
+            const int piece = sl < B_PIECES ? sl : 0;
+            const int nt = piece / 3, term = piece - nt * 3;
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.bank + (int64_t)nt * img_bytes + ((int64_t)c * 3 + term) * 1024 + lane * 16),
+                                             (lptr_t)(dst + sl * 1024), 16, 0, 0);
+        }
+    };
+    u32x4_t A0[WD_R], A1[WD_R], A2[WD_R];                           // the A fragments of chunks = 0, 1, 2 (mod 3)
+    f32x4_t acc[WD_R * NT];
+#pragma unroll
+    for (int q = 0; q < WD_R * NT; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int c, const u32x4_t (&A)[WD_R]) {
+        const unsigned b_base = (unsigned)(uintptr_t)(smem + (c % RING) * SLOT) + lane * 16;
+        // steps = the three terms; B fragments of term t+1 are requested before the MFMAs of term t
+        u32x4_t Bf[2][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm_lds16<0>(Bf[0][nt], b_base + (nt * 3 + 0) * 1024);
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+            const int cur = term & 1, nxt = cur ^ 1;
+            if (term + 1 < 3) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) asm_lds16<0>(Bf[nxt][nt], b_base + (nt * 3 + term + 1) * 1024);
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT) : "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            asm_touch<0, NT>(Bf[cur]);
+#pragma unroll
+            for (int r = 0; r < WD_R; ++r)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[r * NT + nt] = moc_mfma_half<F16>(A[r], Bf[cur][nt], acc[r * NT + nt]);
+        }
+    };
+    // chunk c = g + J of the group of three starting at g: its A fragments sit at byte offset J*64 of rp[] (which
+    // advances by 192 per group); the request for chunk c+2 uses offset (J+2)*64 of the same base
+#define MOC_WIDE_REQ(CH, AREG, OFF)                                                                     \
+    do {                                                                                                \
+        issue_image(CH);                                                                                \
+        asm_load16<OFF>(AREG[0], rp[0]); asm_load16<OFF>(AREG[1], rp[1]);                               \
+        asm_load16<OFF>(AREG[2], rp[2]); asm_load16<OFF>(AREG[3], rp[3]);                               \
+    } while (0)
+#define MOC_WIDE_STEP(J, ACUR, ANEXT2)                                                                  \
+    do {                                                                                                \
+        const int c = g + J;                                                                            \
+        if (c < nchunk) {                                                                               \
+            if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");                \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+            asm_touch<0, WD_R>(ACUR);                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          \
+            __builtin_amdgcn_s_barrier();                                                               \
+            if (c + 2 < nchunk) MOC_WIDE_REQ(c + 2, ANEXT2, (J + 2) * 64);                              \
+            compute(c, ACUR);                                                                           \
+        }                                                                                               \
+    } while (0)
+    static_assert(WD_R == 4, "MOC_WIDE_REQ spells out four row tiles");
+    MOC_WIDE_REQ(0, A0, 0);
+    MOC_WIDE_REQ(1, A1, 64);
+    for (int g = 0; g < nchunk; g += 3) {
+        MOC_WIDE_STEP(0, A0, A2);
+        MOC_WIDE_STEP(1, A1, A0);
+        MOC_WIDE_STEP(2, A2, A1);
+#pragma unroll
+        for (int r = 0; r < WD_R; ++r) rp[r] += 192;
+    }
+#undef MOC_WIDE_STEP
+#undef MOC_WIDE_REQ
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                   // the ring is free: the epilogue's tiles reuse it
+    // ---- epilogue: one row tile at a time through the wave's LDS tile
+#pragma unroll
+    for (int r = 0; r < WD_R; ++r) {
+        const int row0 = wg_row0 + (wave * WD_R + r) * 16;
+        if (row0 >= nk) break;                                      // wave-uniform
+        wave_lds_order();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tile[((lane >> 4) * 4 + i) * LDT + nt * 16 + (lane & 15)] = acc[r * NT + nt][i] * a.oscale;
+        wave_lds_order();
+        row_epilogue_wide<NT>(a, tile, base, row0, nk);
+    }
+}
+
 // Row statistics from a given logits matrix [N, Ct] (row-major): same columns as the score
 // pass writes.  One thread per row; used by the helpers that take logits, not bags.
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* logits, int64_t N, int Ct, int C,
@@ -860,6 +999,26 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
             if (f16) scores_wide_kernel<NTT, true><<<grid_w, 256, smem_w, s>>>(a);                      \
             else scores_wide_kernel<NTT, false><<<grid_w, 256, smem_w, s>>>(a);                         \
         } while (0)
+        if (a.NT <= 5) {                                               // (6 n-tiles: the register ring spills)
+            const size_t ring = (size_t)3 * ((size_t)((a.NT * 3 + 3) / 4) * 4 * 1024);         // three image slots
+            const size_t smem_r = ring > tiles ? ring : tiles;
+#define MOC_LAUNCH_RING(NTT)                                                                            \
+            do {                                                                                        \
+                static bool attr_set[2] = {false, false};                                               \
+                if (!attr_set[f16]) {                                                                   \
+                    if (f16) (void)hipFuncSetAttribute((const void*)scores_wide_ring_kernel<NTT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                    else (void)hipFuncSetAttribute((const void*)scores_wide_ring_kernel<NTT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                    attr_set[f16] = true;                                                               \
+                }                                                                                       \
+                if (f16) scores_wide_ring_kernel<NTT, true><<<grid_w, 256, smem_r, s>>>(a);             \
+                else scores_wide_ring_kernel<NTT, false><<<grid_w, 256, smem_r, s>>>(a);                \
+            } while (0)
+            if (a.NT == 4) MOC_LAUNCH_RING(4);
+            else MOC_LAUNCH_RING(5);
+#undef MOC_LAUNCH_RING
+            MOC_CHECK_LAUNCH("moc_scores(wide ring)");
+            return MOC_OK;
+        }
         if (smem_w < 160 * 1024) {
             switch (a.NT) {
                 case 4: MOC_LAUNCH_WIDE(4); break;

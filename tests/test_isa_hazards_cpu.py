@@ -39,6 +39,14 @@ def _check_kernel(name, lines, precise=True):
         if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
             continue
         toks = re.findall(r"v\[\d+:\d+\]|v\d+", t)
+        if t.startswith("global_load_lds"):
+            # an LDS-DMA (the compiler's builtin, not asm): no destination register, but it takes a place in the in-order
+            # vector-memory queue that the counted waits retire -- the wide ring kernel mixes them with register loads
+            in_flight = set().union(*pend["vm"], *pend["lgkm"]) if (pend["vm"] or pend["lgkm"]) else set()
+            addr = set().union(*[_regs(x) for x in toks]) if toks else set()
+            assert not (addr & in_flight), f"{name}: `{t}` takes its address from in-flight registers"
+            pend["vm"].append(set())
+            continue
         kind = "vm" if t.startswith("global_load_dwordx4") else "lgkm" if t.startswith("ds_read_b128") else None
         if in_asm and kind:
             in_flight = set().union(*pend["vm"], *pend["lgkm"]) if (pend["vm"] or pend["lgkm"]) else set()
@@ -72,7 +80,7 @@ def test_no_instruction_touches_inflight_asm_load_registers(tmp_path):
     text = asm.read_text().splitlines()
     kernels, cur, name = {}, None, None
     for ln in text:
-        m = re.match(r"^(_ZN\S*scores_(?:stream|wide)_kernel\S*):", ln)
+        m = re.match(r"^(_ZN\S*scores_(?:stream|wide|wide_ring)_kernel\S*):", ln)
         if m:
             name, cur = m.group(1), []
             continue
