@@ -88,6 +88,10 @@ def parse():
                     help="--train-mode dp: strong = the same --slides slides sharded over the ranks (the BASELINE metric); "
                          "weak = every rank its own --slides slides")
     ap.add_argument("--no-dp-extra", action="store_true", help="N > 1, seq: skip the minibatch_dp extra block")
+    ap.add_argument("--dp-exchange", default="rccl", choices=["rccl", "auto"],
+                    help="minibatch data parallelism: rccl = ONE RCCL all-reduce of the flat meta-gradient per step (default: "
+                         "the collective is the path that needs no peer mapping); auto = the sum inside the step kernel over "
+                         "peer-mapped xGMI buffers when its two set-up self-checks pass, else the collective")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel trainer even at 1 GPU (rehearsal)")
     ap.add_argument("--force-seq", action="store_true", help="run the exact-sequential multi-GPU trainer even at 1 GPU "
                                                               "(rehearsal: what its pack / gather / compact-batch machinery costs)")
@@ -179,6 +183,7 @@ def main():
     cpus = granted_cpus()
     torch.set_num_threads(max(1, min(8, cpus // max(1, world))))   # the GPU leg's host side is serial
     import torch.distributed as dist
+    os.environ["MOC_DP_EXCHANGE"] = a.dp_exchange
     dp = world > 1 or a.force_dp
     if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -440,13 +445,17 @@ def main():
         for omode in todo:
             per = a.slides if omode == "dp_weak" else a.slides // world
             k2 = max(per, min(a.steps, 10 * per))
-            r2 = measure(omode, k2, min(a.warmup, per), 0)
+            try:
+                r2 = measure(omode, k2, min(a.warmup, per), 0)
+            except Exception as e:  # noqa: BLE001 -- an extra block must not cost the line its `value`
+                extras[omode] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                continue
             extras[omode] = {"value": round(r2["value"], 1), "unit": "meta-steps/s (slides consumed by all ranks)",
                              "sync_steps": k2, "ms_per_sync_step": round(r2["dt"] / k2 * 1e3, 5), "exchange": r2["exchange"]}
             if r2["fallback"]:
                 extras[omode]["exchange_fallback"] = r2["fallback"]
-            res, model = r2["res"], r2["model"]
-            r2["loop"] = None
+            model = r2["model"]
+            r2["loop"] = r2["res"] = None
 
     # ---- evaluation throughput (slides/sec), batched end to end; slides sharded over the ranks, no data-path collective
     eval_rate = None
