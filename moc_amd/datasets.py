@@ -188,9 +188,6 @@ def to_sharded(split: Generic_Split, device, rank: int, world: int, dtype=None, 
     sizes = [v for part in box for v in part]
     sh = mdist.SeqShardedBags(bags, sizes, labels, device, rank, world, dtype=dtype, paths=paths)
     if split.repeat_num and split.repeat_num != n:
-        if split.repeat_num > n:
-            raise NotImplementedError("multi-GPU training visits every slide at most once per epoch "
-                                      f"(repeat_num {split.repeat_num} > {n} slides in the split)")
         sh.repeat_num = split.repeat_num
     return sh
 

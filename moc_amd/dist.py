@@ -570,7 +570,7 @@ def _seq_plan(sh: SeqShardedBags, m: int, bank, args):
     plan = sh._plans.get(key)
     if plan is not None:
         return plan
-    assert m <= sh.real_len(), "train_seq: repeat_num beyond the split's slides is not supported"
+    assert m <= sh.real_len()                                   # (longer passes are split into rounds by train_seq)
     dev, per, world = sh.device, sh.per, sh.world
     n_loc = max(0, min(m, sh.hi) - sh.lo)                       # this rank's slides among the pass's first m visits
     cap = min(args.topj * (2 * bank.C + 2), max(sh.all_sizes))  # a slide selects at most this many rows
@@ -684,6 +684,25 @@ def train_seq(model, shard: SeqShardedBags, optimizer, device, args, group=None)
     from . import engine, main_moc as M
     if not model.training:
         model.train()
+    m_all, n_real = len(shard), shard.real_len()
+    if m_all > n_real:
+        # repeat_num beyond the split (datasets/dataset_generic.py:380-393: visit v is slide v mod n): whole rounds over
+        # the slides, then the remainder -- each round a pass of its own, in order, the mask stream running on
+        rounds = [n_real] * (m_all // n_real) + ([m_all % n_real] if m_all % n_real else [])
+        keep_rep, keep_next = shard.repeat_num, shard.next_pass_len
+        try:
+            for i, L in enumerate(rounds):
+                shard.repeat_num = None if L == n_real else L
+                if i + 1 < len(rounds):
+                    shard.next_pass_len = rounds[i + 1]
+                elif keep_next == 0:
+                    shard.next_pass_len = 0
+                else:                                   # the next call's first round
+                    shard.next_pass_len = min(n_real, keep_next if keep_next is not None else m_all)
+                train_seq(model, shard, optimizer, device, args, group)
+        finally:
+            shard.repeat_num, shard.next_pass_len = keep_rep, keep_next
+        return
     use = engine.train_use_bits(args.discard_classifiers)
     X_like = shard.local.X if shard.local is not None else None
     assert X_like is not None, "train_seq: every rank must hold at least one slide"
@@ -716,6 +735,8 @@ def train_seq(model, shard: SeqShardedBags, optimizer, device, args, group=None)
     hint = shard.next_pass_len
     if not M.PREFETCH_PHASE_A or hint == 0:
         return
+    if hint is not None:
+        hint = min(hint, shard.real_len())              # (a longer pass starts with a whole round)
     nplan = plan
     if hint is not None and hint != m:
         nplan = _seq_plan(shard, hint, bank, args)

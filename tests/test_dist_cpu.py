@@ -146,3 +146,55 @@ def test_sharded_eval_gather_world2():
     out = _run(_gather_worker, 2)
     exp = np.array([[10.0 * i + c for c in range(3)] + [float(i)] for i in range(7)], dtype=np.float32)
     assert np.array_equal(out[0], exp) and np.array_equal(out[1], exp)
+
+
+# ------------------------------------------------------------------ splits spread over the ranks (round 2)
+def test_block_lists_are_contiguous_and_partition():
+    for n, w in [(7, 3), (32, 8), (5, 8), (48, 4), (1, 2)]:
+        blocks = mdist.block_lists(n, w)
+        assert len(blocks) == w and sum(blocks, []) == list(range(n))
+        per = (n + w - 1) // w
+        assert all(len(b) <= per for b in blocks)
+    with pytest.raises(AssertionError, match="partition"):
+        mdist.ShardedSplit([], [], [0, 1, 0], [[0, 1], [1, 2]], "cpu")
+
+
+def _sharded_driver_inputs(rank, world, root):
+    """Every rank reads only its block of each split (datasets.to_sharded); the train split's row counts are
+    exchanged through the process group; labels and the partition are the same everywhere."""
+    import pandas as pd
+    from moc_amd import datasets as DS
+    ds = DS.Generic_MIL_Dataset(csv_path=os.path.join(root, "t.csv"), data_dir=os.path.join(root, "bags"), print_info=False,
+                                label_dict={"A": 0, "B": 1})
+    tr, va, te = ds.return_splits(from_id=False, csv_path=os.path.join(root, "splits_0.csv"), repeat_num=7)
+    train = DS.to_sharded(tr, "cpu", rank, world, train=True)
+    val = DS.to_sharded(va, "cpu", rank, world)
+    return dict(lo=train.lo, hi=train.hi, per=train.per, all_sizes=train.all_sizes, my_ids=train.my_ids, labels=train.all_labels,
+                n_local=0 if train.local is None else len(train.local.sizes), local_sizes=[] if train.local is None else train.local.sizes,
+                val_ids=val.my_ids, val_lists=val.index_lists, val_local=None if val.local is None else val.local.sizes,
+                repeat=train.repeat_num, length=len(train))
+
+
+def test_to_sharded_reads_blocks_and_agrees_on_the_layout(tmp_path):
+    import pandas as pd
+    from moc_amd import datasets as DS
+    sizes = [30, 45, 12, 60, 25, 33, 51]
+    rows = []
+    for i, n in enumerate(sizes):
+        sid = f"s{i}"
+        DS.write_bag(str(tmp_path / "bags"), sid, torch.randn(n, 256), fmt="pt" if i % 2 else "npy")
+        rows.append((f"p{i}", sid, "A" if i % 2 else "B"))
+    for i in range(3):
+        DS.write_bag(str(tmp_path / "bags"), f"v{i}", torch.randn(10 + i, 256), fmt="npy")
+        rows.append((f"pv{i}", f"v{i}", "A"))
+    pd.DataFrame(rows, columns=["case_id", "slide_id", "label"]).to_csv(tmp_path / "t.csv", index=False)
+    pd.DataFrame({"train": pd.Series([f"s{i}" for i in range(7)]), "val": pd.Series([f"v{i}" for i in range(3)]),
+                  "test": pd.Series([f"v{i}" for i in range(3)])}).to_csv(tmp_path / "splits_0.csv")
+    out = _run(_sharded_driver_inputs, 2, str(tmp_path))
+    for r in (0, 1):
+        assert out[r]["all_sizes"] == sizes and out[r]["labels"] == [1, 0, 1, 0, 1, 0, 1] and out[r]["per"] == 4
+        assert out[r]["repeat"] is None and out[r]["length"] == 7          # repeat_num == number of slides: plain epochs
+        assert out[r]["val_lists"] == [[0, 1], [2]]
+    assert (out[0]["lo"], out[0]["hi"], out[1]["lo"], out[1]["hi"]) == (0, 4, 4, 7)
+    assert out[0]["local_sizes"] == sizes[:4] and out[1]["local_sizes"] == sizes[4:]
+    assert out[0]["val_local"] == [10, 11] and out[1]["val_local"] == [12]

@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 SIZES = [900, 1100, 1000, 800, 950, 1050, 700]
-PASSES = [None, None, 5, None]          # repeat_num per pass (None = all slides): a partial pass in the middle
+PASSES = [None, None, 5, None, 10]      # repeat_num per pass (None = all 7 slides): a partial pass in the middle, a wrapping one (7 + 3) last
 
 
 def _free_port():
@@ -46,7 +46,8 @@ def _single_gpu(dev, C, j, K, store):
         res.repeat_num = rn
         M.train(model, res, opt, dev, H.make_args(C, j, K))
         torch.cuda.synchronize()
-        losses.append(M.train.last[0].meta_ws()[0]["loss"][:len(res)].cpu().numpy().copy())
+        m_last = len(res) % len(SIZES) or len(SIZES)
+        losses.append(M.train.last[0].meta_ws()[0]["loss"][len(res) - m_last:len(res)].cpu().numpy().copy())
     return H.flat_params(model), losses, torch.get_rng_state(), H.flat_state(opt, "exp_avg_sq")
 
 
@@ -70,7 +71,8 @@ def _seq_run(dev, rank, world, C, j, K, store, group=None, hints=True):
             sh.next_pass_len = (nxt or len(SIZES)) if nxt != 0 else 0
         mdist.train_seq(model, sh, opt, dev, H.make_args(C, j, K), group=group)
         torch.cuda.synchronize()
-        losses.append(mdist.train_seq.last[0].meta_ws()[0]["loss"][:len(sh)].cpu().numpy().copy())
+        m_last = len(sh) % len(SIZES) or len(SIZES)               # (a wrapping pass runs as rounds: the last round's losses)
+        losses.append(mdist.train_seq.last[0].meta_ws()[0]["loss"][:m_last].cpu().numpy().copy())
     return H.flat_params(model), losses, torch.get_rng_state(), H.flat_state(opt, "exp_avg_sq")
 
 
@@ -171,20 +173,16 @@ def synth_bank(seed, C):
     return synth.make_bank(seed, 512, C)
 
 
-@pytest.mark.parametrize("cid", [0])
+@pytest.mark.parametrize("cid", [0, 1])
 def test_two_rank_driver_reproduces_the_reference_main_fixture(gpu_device, tmp_path, cid):
     """run_moc.main() with every split spread over two ranks (train: exact-sequential; evaluations: sharded + gathered)
     against what the reference's own main() produced on the CPU for the same task (tests/golden/driver.npz): per-epoch
     validation AUC within +-0.002, same best epoch / test AUC / accuracy, zero-shot results, result files written by
-    rank 0.  (Case 1 of the fixture visits its 6 train slides 9 times per epoch -- repeat_num beyond the split, which
-    the multi-GPU mode refuses; it stays a single-GPU case in test_gpu_driver.py.)"""
+    rank 0.  Case 1 visits its 6 train slides 9 times per epoch (repeat_num beyond the split: a round of 6 and one of 3)."""
     import helpers as H
     import json
     from test_gpu_driver import _task_on_disk
     g = H.golden("driver")
-    rep, ntr = int(g["cases"][cid][7]), int(g["cases"][cid][1])
-    if rep > ntr:
-        pytest.skip("fixture visits slides more than once per epoch (repeat_num > slides): single-GPU only")
     _task_on_disk(str(tmp_path), cid, g)
     world = 2
     ctx = mp.get_context("spawn")
