@@ -2,7 +2,9 @@
 counts, dims, storage types, ragged slide sizes, topj / topk and discarded selectors.
 
   draw_case(rng, idx)  -> a fully explicit case (plain dict, JSON-able): every seed and size spelled out
-  run_case(case, dev)  -> "ok" | ("set aside", reason); raises AssertionError on a real disagreement
+  run_case(case, dev)  -> "ok" | ("set aside", reason); raises AssertionError on a real disagreement.  Before the two
+                          epochs it compares the element-wise gradients of the case's largest slide with autograd on
+                          the oracle at 2e-6 (gradient_check: no Adam step, so nothing can hide in Adam's noise bound)
 
 tests/test_gpu_fuzz.py replays the committed list tests/golden/fuzz_cases.json under `pytest -m gpu`;
 scripts/fuzz_parity.py draws fresh cases.  A case is SET ASIDE -- never silently, the reason and its margin are returned
@@ -84,6 +86,47 @@ def topk_margin(seed, D, ref_bags, labels, W, We, C, j, K, discard):
     return gap
 
 
+def gradient_check(c, dev, W, We, bags, ref_bags, labels, model, ref_model):
+    """Element-wise gradients of ONE slide (no mask, no Adam step in between): moc_train_grad against autograd on the
+    oracle at 2e-6 absolute / 1e-4 relative.  Adam's noise bound on the parameters (helpers.assert_adam_params_close)
+    tolerates up to lr * step on elements whose gradient is at the noise floor; a sign or scale error on such elements
+    would hide there -- not here.  A mismatch is excused (the reason is returned) only when the oracle's own margins
+    make the slide undefined: a selector boundary, a top-K boundary or a pooled row's ReLU within rounding."""
+    from moc_amd import engine as E, main_moc as M
+    C, D, K, j, discard = c["C"], c["D"], c["K"], c["j"], c["discard"]
+    i = max(range(len(bags)), key=lambda k: bags[k].size(0))           # the largest slide of the case
+    x = ref_bags[i]
+    sr = O.slide_process(x, W, We, C, j, mask=None, discard=discard)
+    mixed = O.mix_train(ref_model(sr["selected_feat"]), sr, discard)
+    k = min(K, mixed.size(0))
+    pooled = O.pool_top(mixed, [K])[1][K]
+    loss = torch.nn.functional.cross_entropy(pooled, torch.tensor([labels[i]]))
+    exp = torch.cat([t.reshape(-1) for t in torch.autograd.grad(loss, list(ref_model.parameters()))]).numpy()
+    X = bags[i].to(dev).contiguous()
+    batch = E.SlideBatch(X, [X.size(0)], C, C + 4, j, K, discard)
+    batch.phase_a(E.Bank.get(M.zeroshot_weights, M.zeroshot_weights_ext, X.dtype, dev))
+    lab = torch.tensor([labels[i]], dtype=torch.int64, device=dev)
+    meta = E.MetaState(model, None, need_grads=True)
+    E.train_grad(batch, meta, lab, 0, E.train_use_bits(discard))
+    got = torch.cat([t.reshape(-1) for t in meta.grads]).cpu().numpy()
+    try:
+        np.testing.assert_allclose(got, exp, atol=2e-6, rtol=1e-4, err_msg=describe(c) + f": gradients of slide {i}")
+    except AssertionError:
+        if boundary_margin(x, W, We, C, j) < 1e-6:
+            return "selection boundary tie on that slide"
+        if mixed.size(0) > k:
+            srt = mixed.detach().sort(0, descending=True).values
+            if float((srt[k - 1] - srt[k]).min()) < 5e-6:
+                return "top-K boundary tie on that slide"
+        with torch.no_grad():
+            h = ref_model.model[0](sr["selected_feat"])
+            idx = mixed.detach().topk(k, 0).indices.reshape(-1).unique()
+            if float(h[idx].abs().min()) < 2e-6:
+                return "ReLU boundary on a pooled row"
+        raise
+    return None
+
+
 def run_case(c, dev):
     from moc_amd import main_moc as M
     C, D, K, j, sizes, discard, labels, seed = c["C"], c["D"], c["K"], c["j"], c["sizes"], c["discard"], c["labels"], c["seed"]
@@ -101,6 +144,7 @@ def run_case(c, dev):
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
     M.set_classifier_bank(W.to(dev), We.to(dev))
     args = H.make_args(C, j, K, discard)
+    c["_grad_check"] = gradient_check(c, dev, W, We, bags, ref_bags, labels, model, ref_model) or "compared"
     res = M.ResidentBags(bags, labels, dev)
     for epoch in range(2):
         torch.manual_seed(seed + 1 + epoch)
