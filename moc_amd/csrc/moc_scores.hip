@@ -679,8 +679,9 @@ __global__ __launch_bounds__(256, (NT <= 6 ? 2 : 1)) void scores_wide_kernel(Sco
 // The double-buffered kernel above waits, once per 32-column chunk, for a DMA it issued one chunk (~1,000 cycles of
 // MFMAs) earlier; two workgroups per CU cover for each other (3.2 TB/s with nothing stored, against 10 TB/s of MFMA
 // rate).  Measured +5 % over it at 5 n-tiles (2.94 against 2.81 TB/s on 64 x 50 k x 1024 fp16, 3.07 against 2.86
-// unmasked): what is left is not the look-ahead -- every row arrives as 32 separate 64-byte pieces, one per chunk,
-// and HBM serves such pieces far below its streaming rate.  Here
+// unmasked): what is left is neither the look-ahead nor the 64-byte pieces the rows arrive in (a read-only sweep in
+// the same order reaches 6.1 TB/s, scripts/native/piece_bench.hip) but the per-chunk bubble and the serial row epilogue
+// (DESIGN.md section 12).  Here
 //   * the image slices go through a ring of THREE LDS slots (16 KiB each at 5 n-tiles), loaded by LDS-DMA;
 //   * the A fragments do not touch LDS at all: every wave loads its own four row tiles' 16-B pieces straight into a
 //     ring of three register sets (asm loads the compiler does not see), two chunks ahead (a fourth set spills);
