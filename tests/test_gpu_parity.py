@@ -611,6 +611,8 @@ def test_batched_forward_is_bit_identical_to_one_slide_at_a_time(dev, dtype, D):
     (64, 10, 30, 1024, torch.float16, [900] * 64),               # the 64-way x 1024-d shape: wide step kernel, 640 pairs
     (40, 16, 40, 512, torch.float32, [800] * 40),                # fp32 storage, 640 pairs of 16 per class
     (20, 7, 400, 512, torch.bfloat16, [9000, 8000] * 10),        # S ~ 6-8 k selected rows (8 scores per thread)
+    (2, 10, 400, 512, torch.bfloat16, [60000, 2000, 33]),        # the largest bag of the synthetic recipe (clipped at 60 k) beside small ones
+    (3, 10, 10, 512, torch.float32, [60000, 17]),                # ... fp32 storage, the reference's default topj
 ])
 def test_train_and_eval_match_oracle_on_odd_shapes(dev, C, K, j, D, dtype, sizes):
     M = _mm()
