@@ -20,7 +20,8 @@ Minibatch data parallelism (`--train-mode dp`: one slide per rank per synchronou
 the ranks, one Adam step per N slides) is faster but changes the trajectory -- measured AUC deviations of 0.01-0.2
 from the sequential run at every N and learning-rate rule (profiles/round2_dp_auc_study.jsonl), outside the +-0.002
 bar -- so it is an opt-in extension; a default N > 1 run reports it under `minibatch_dp` (strong: the same slides
-sharded, `--scaling`; weak: every rank its own) from shorter runs of the same process.
+sharded, `--scaling`; weak: every rank its own) from shorter runs of the same process, and under `replicas` what N
+independent runs (one per GPU, no communication: the reference's scripts/moc_train.sh) deliver together.
 
 Prints ONE JSON line on rank 0.  Extra keys: steady_state (>= 50 whole epochs of the same model in the
 same run: what a training run of many epochs sees, whatever --steps was), roofline (dominant kernel =
@@ -92,6 +93,10 @@ def parse():
                     help="minibatch data parallelism: rccl = ONE RCCL all-reduce of the flat meta-gradient per step (default: "
                          "the collective is the path that needs no peer mapping); auto = the sum inside the step kernel over "
                          "peer-mapped xGMI buffers when its two set-up self-checks pass, else the collective")
+    ap.add_argument("--packed-runs", type=int, default=4,
+                    help="N = 1: also measure this many independent training runs side by side on the ONE GPU (separate processes, "
+                         "as scripts/moc_train.sh of the reference packs five folds onto a GPU); 0 = skip")
+    ap.add_argument("--replicas-only", action="store_true", help=argparse.SUPPRESS)      # the child of --packed-runs
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel trainer even at 1 GPU (rehearsal)")
     ap.add_argument("--force-seq", action="store_true", help="run the exact-sequential multi-GPU trainer even at 1 GPU "
                                                               "(rehearsal: what its pack / gather / compact-batch machinery costs)")
@@ -314,7 +319,7 @@ def main():
         res = make_split(mode)
         model, opt = new_model()
         loop = Loop(res, model, opt, mode)
-        units = world if mode in ("dp_strong", "dp_weak") else 1     # slides one step consumes, over the whole job
+        units = world if mode in ("dp_strong", "dp_weak", "replicas") else 1     # slides one step consumes, over the whole job
         warm, timed = loop.schedule(n_warm), loop.schedule(n_steps)
         steady = [loop.per_pass] * steady_epochs
         loop.allocate(warm + timed + steady)
@@ -336,7 +341,7 @@ def main():
         loop.run(warm, then=timed[0])
         fence()
         exchange = getattr(mdist.train_dp, "exchange", None) if mode.startswith("dp") else None
-        if world > 1 and not ranks_agree(model):
+        if world > 1 and mode != "replicas" and not ranks_agree(model):
             # the in-kernel exchange misbehaved on this node: fall back to the RCCL collective, from scratch
             err = mdist.exchange_error()
             if rank == 0:
@@ -359,7 +364,7 @@ def main():
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
         ev = list(engine.SCORE_EVENTS) if engine.SCORE_EVENTS is not None else []
-        assert ranks_agree(model), "data-parallel ranks ended the timed region with different parameters"
+        assert mode == "replicas" or ranks_agree(model), "data-parallel ranks ended the timed region with different parameters"
         out = {"value": n_steps * units / dt, "dt": dt, "loop": loop, "exchange": exchange, "fallback": fallback,
                "events": ev, "steady": None, "res": res, "model": model}
         if steady:
@@ -376,9 +381,19 @@ def main():
                              "steps": n, "ms_per_step": round(sdt / n * 1e3, 5),
                              "note": "whole epochs of the same model right after the timed region (same process, same "
                                      "clocks): the rate a run of many epochs sees"}
-            assert ranks_agree(model), "data-parallel ranks ended the steady-state block with different parameters"
+            assert mode == "replicas" or ranks_agree(model), "data-parallel ranks ended the steady-state block with different parameters"
         return out
 
+    if a.replicas_only:
+        # child of `--packed-runs`: `world` independent runs, timed together; one small JSON line
+        r3 = measure("replicas", a.steps, a.warmup, 0)
+        if rank == 0:
+            os.write(real_stdout, (json.dumps({"runs": world, "value": round(r3["value"], 1), "steps_per_run": a.steps,
+                                               "ms_per_step_per_run": round(r3["dt"] / a.steps * 1e3, 5)}) + "\n").encode())
+        if dp:
+            mdist.shutdown()
+            dist.destroy_process_group()
+        return
     engine.SCORE_EVENTS = []          # (start, stop, algorithmic bytes) per score-pass launch
     if world == 1:
         main_mode = "dp_weak" if a.force_dp else "seq" if a.force_seq else "single"
@@ -457,6 +472,21 @@ def main():
             model = r2["model"]
             r2["loop"] = r2["res"] = None
 
+    # ---- N independent runs, one per GPU, no communication at all: how the reference itself uses several GPUs
+    # (scripts/moc_train.sh gives every fold x shot its own process and GPU) -- every run the reference's trajectory
+    replicas = None
+    if world > 1 and not a.no_dp_extra:
+        try:
+            k3 = max(a.slides, min(a.steps, 10 * a.slides))
+            r3 = measure("replicas", k3, min(a.warmup, a.slides), 0)
+            replicas = {"value": round(r3["value"], 1), "unit": "meta-steps/s (all runs together)", "steps_per_run": k3,
+                        "ms_per_step_per_run": round(r3["dt"] / k3 * 1e3, 5), "scaling": "weak",
+                        "note": f"{world} independent training runs ({a.slides} slides of its own each), one per GPU, no collective: "
+                                "the reference's own way of filling a node (scripts/moc_train.sh: one process per fold x shot)"}
+            r3["loop"] = r3["res"] = None
+        except Exception as e:  # noqa: BLE001
+            replicas = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     # ---- evaluation throughput (slides/sec), batched end to end; slides sharded over the ranks, no data-path collective
     eval_rate = None
     if not a.no_eval:
@@ -483,6 +513,29 @@ def main():
         edt = max_over_ranks(time.perf_counter() - t0)
         eval_rate = reps * n_eval / edt
         del eres
+
+    # ---- several independent runs side by side on this ONE GPU (separate processes; nothing of this process runs meanwhile)
+    packed = None
+    if world == 1 and a.packed_runs > 1 and not (a.force_dp or a.force_seq):
+        torch.cuda.synchronize()
+        k3 = max(a.slides, min(a.steps, 20 * a.slides))
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(a.packed_runs), "--replicas-only", "--steps", str(k3),
+               "--warmup", str(a.slides), "--dtype", a.dtype, "--slides", str(a.slides), "--patches", str(a.patches),
+               "--classes", str(C), "--dim", str(D), "--topj", str(j), "--topk", str(K)] + (["--lognormal"] if a.lognormal else [])
+        env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+        env["MOC_BENCH_ONE_DEVICE"] = "1"
+        try:
+            cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+            line = [ln for ln in cp.stdout.decode().splitlines() if ln.startswith("{")]
+            packed = json.loads(line[-1]) if cp.returncode == 0 and line else {"error": f"child exited {cp.returncode}"}
+        except Exception as e:  # noqa: BLE001 -- an extra block must not cost the line its `value`
+            packed = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if "value" in packed:
+            packed.update(unit="meta-steps/s (all runs together, ONE GPU)",
+                          vs_one_run=round(packed["value"] / value, 2),
+                          note=f"{a.packed_runs} independent training runs as separate processes on the same GPU -- the reference's "
+                               "scripts/moc_train.sh packs five folds onto one GPU; moc_amd.run_many is its job queue.  One run is a "
+                               "latency chain that leaves most of the GPU idle; independent runs interleave")
 
     # ---- CPU baseline: the oracle's train loop on the host cores (rank 0, N=1 only)
     cpu = None
@@ -538,6 +591,10 @@ def main():
             "eval_slides_per_sec": None if eval_rate is None else round(eval_rate, 1),
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if replicas:
+            out["replicas"] = replicas
+        if packed:
+            out["packed_runs"] = packed
         if extras:
             out["minibatch_dp" if main_mode == "seq" else "other_modes"] = dict(
                 extras, note="synchronous minibatch data parallelism: one Adam step per N slides -- an opt-in extension "

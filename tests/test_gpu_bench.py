@@ -25,7 +25,7 @@ def _bench(*args, env=None, timeout=600):
 
 
 def test_one_gpu_line(gpu_device):
-    d = _bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2", "--steady-epochs", "10")
+    d = _bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2", "--steady-epochs", "10", "--packed-runs", "2")
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "meta-steps/s"
     assert d["value"] > 5000 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1.0
     assert d["config"]["workload"].startswith("NSCLC 2-way 16-shot") and d["dtype"] == "f32" and d["vs_baseline"] is None
@@ -38,6 +38,8 @@ def test_one_gpu_line(gpu_device):
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 10 and cpu["cores"] >= 1 and "sample" in cpu
     assert d["eval_slides_per_sec"] > 10000
+    pk = d["packed_runs"]
+    assert pk["runs"] == 2 and pk["value"] > 5000 and "vs_one_run" in pk      # two independent runs on the one GPU, timed together
 
 
 def test_gpus_2_starts_its_own_ranks_and_reports_the_exact_sequential_mode(gpu_device):
@@ -49,3 +51,5 @@ def test_gpus_2_starts_its_own_ranks_and_reports_the_exact_sequential_mode(gpu_d
     mb = d["minibatch_dp"]
     assert mb["dp_strong"]["value"] > 100 and mb["dp_weak"]["value"] > 100 and mb["dp_strong"]["exchange"] == "p2p"
     assert "NOT within" in mb["note"]
+    rep = d["replicas"]
+    assert rep["value"] > 100 and rep["scaling"] == "weak" and "no collective" in rep["note"]
