@@ -84,6 +84,8 @@ def main(argv=None):
                 os.makedirs(out_dir, exist_ok=True)
                 env = dict(os.environ, HIP_VISIBLE_DEVICES=str(key[0]), CUDA_VISIBLE_DEVICES=str(key[0]))
                 env.pop("ROCR_VISIBLE_DEVICES", None)
+                pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))     # `-m moc_amd.run_moc` from any cwd
+                env["PYTHONPATH"] = pkg_parent + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
                 fh = open(log, "a")
                 proc = subprocess.Popen(cmd, stdout=fh, stderr=subprocess.STDOUT, env=env)
                 slots[key] = (proc, shot, fold, fh, time.time())

@@ -119,3 +119,19 @@ def test_file_backed_dataloader_equals_resident(gpu_device, tmp_path):
     np.testing.assert_array_equal(out[0][0], out[1][0])
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
     assert torch.equal(out[0][3], out[1][3]), "the two paths leave the CPU generator in different states"
+
+
+def test_run_many_packs_runs_onto_the_gpu(gpu_device, tmp_path):
+    """moc_amd.run_many (the reference's scripts/moc_train.sh as a job queue) with real moc_amd.run_moc processes: two
+    folds side by side on the one GPU, each a whole (short) synthetic run; result files per fold where the reference's
+    script puts them."""
+    from moc_amd import run_many
+    rc = run_many.main(["--folds", "0", "1", "--shots", "2", "--gpus", "0", "--runs-per-gpu", "2", "--seed", "3",
+                        "--result_dir", str(tmp_path / "res"), "--", "--synthetic", "6", "--epochs", "2", "--disable_tqdm",
+                        "--topj", "100", "--topk", "5"])
+    assert rc == 0
+    d = tmp_path / "res" / "2_shot"
+    for fold in (0, 1):
+        best = json.load(open(d / f"best_results_shot_2_fold_{fold}.json"))
+        assert 0.0 <= best["best_val"] <= 1.0 and os.path.exists(best["best_model_path"])
+        assert "End training." in open(d / f"fold_{fold}_shot_2_output.txt").read()
