@@ -518,7 +518,7 @@ def main():
     packed = None
     if world == 1 and a.packed_runs > 1 and not (a.force_dp or a.force_seq):
         torch.cuda.synchronize()
-        k3 = max(a.slides, min(a.steps, 20 * a.slides))
+        k3 = 20 * a.slides                      # its own length, whatever --steps is: the block states it (steps_per_run)
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(a.packed_runs), "--replicas-only", "--steps", str(k3),
                "--warmup", str(a.slides), "--dtype", a.dtype, "--slides", str(a.slides), "--patches", str(a.patches),
                "--classes", str(C), "--dim", str(D), "--topj", str(j), "--topk", str(K)] + (["--lognormal"] if a.lognormal else [])
