@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--dump", default=None)
+    ap.add_argument("--wide", action="store_true", help="wide banks (45-76 classes) instead of the standard mix")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(a.seed)
@@ -33,8 +34,8 @@ def main():
     keep = []
     t0 = time.time()
     for i in range(a.cases):
-        c = F.draw_case(rng, i)
-        c["origin"] = f"fuzz seed {a.seed}"
+        c = (F.draw_wide_case if a.wide else F.draw_case)(rng, i)
+        c["origin"] = f"{'wide' if a.wide else 'fuzz'} seed {a.seed}"
         try:
             r = F.run_case(c, dev)
             if r == "ok":

@@ -46,6 +46,25 @@ def draw_case(rng, idx):
             "bank_seed": bank_seed, "bag_seed": bag_seed, "labels": labels, "seed": seed}
 
 
+def draw_wide_case(rng, idx):
+    """Wide banks (45-76 classes: 4-5 n-tiles, the K-split ring kernel on 16-bit storage; the generic score kernel on
+    fp32), added in round 2 with draws of its own so that the (seed, index) pairs of draw_case stay what they were."""
+    C = int(rng.choice([45, 50, 58, 64, 64, 70, 76]))
+    D = int(rng.choice([512, 1024]))
+    dtype = ["bfloat16", "float16", "float16", "float32"][int(rng.integers(0, 4))]
+    K = int(rng.choice([1, 5, 10, 16]))
+    j = int(rng.choice([5, 40, 400]))
+    ns = int(rng.integers(2, 4))
+    sizes = [int(rng.integers(1, 40)) if rng.random() < 0.15 else int(rng.integers(300, 6000)) for _ in range(ns)]
+    discard = [s for s in ["delta_softmax", "delta_diff", "bottomk"] if rng.random() < 0.2]
+    bank_seed = int(rng.integers(1, 1 << 30))
+    bag_seed = int(rng.integers(1, 1 << 30))
+    labels = [int(rng.integers(0, C)) for _ in sizes]
+    seed = int(rng.integers(1, 1 << 30))
+    return {"idx": idx, "C": C, "D": D, "dtype": dtype, "K": K, "j": j, "sizes": sizes, "discard": discard,
+            "bank_seed": bank_seed, "bag_seed": bag_seed, "labels": labels, "seed": seed}
+
+
 def describe(c):
     return (f"#{c['idx']} C={c['C']} D={c['D']} {c['dtype']} K={c['K']} j={c['j']} sizes={c['sizes']} "
             f"discard={c['discard']}" + (f" [{c['origin']}]" if c.get("origin") else ""))

@@ -5,7 +5,8 @@
     draws are reproducible -- with what the sweep reported);
   * a spread drawn from seed 2026: the first cases that add a not-yet-seen (C, dtype), (D, dtype), j, K or discard
     combination, and every case whose union can exceed 4096 / 8192 rows (the wide step kernels' in-kernel pooling and
-    the topk_mean_kernel -> wide step path), then plain draws of seed 2027 until the list holds 64.
+    the topk_mean_kernel -> wide step path), then plain draws of seed 2027 until the list holds 64;
+  * eight wide-bank cases (45-76 classes: the K-split ring kernel, the wide step, the general three-launch step), seed 3030.
 
 No GPU and no reference needed: only the draws are stored, the expected numbers come from the oracle at test time."""
 import json
@@ -60,6 +61,11 @@ def main():
         i += 1
         if sum(c["sizes"]) < 40000:
             out.append(c)
+    rng = np.random.default_rng(3030)                  # ... and eight wide-bank cases (fuzz_core.draw_wide_case)
+    for i in range(8):
+        c = F.draw_wide_case(rng, i)
+        c["origin"], c["expect"] = "wide seed 3030", "ok"
+        out.append(c)
     json.dump(out, open(os.path.join(HERE, "fuzz_cases.json"), "w"), indent=0)
     print(len(out), "cases;", sum(1 for c in out if min(max(c["sizes"]), c["j"] * (2 * c["C"] + 2)) > 8192), "with S bound > 8192")
 
