@@ -183,7 +183,8 @@ def main():
     n_dev = torch.cuda.device_count()
     one_device = os.environ.get("MOC_BENCH_ONE_DEVICE") == "1"     # rehearsal: all ranks on one card (not a measurement)
     assert n_dev >= world or one_device, f"--gpus {world} but this node shows {n_dev} GPU(s)"
-    dev = torch.device("cuda", local_rank % n_dev if one_device else local_rank)
+    # (rehearsal / packed runs: every rank on the SAME card -- device MOC_BENCH_DEVICE, default 0 -- whatever the node has)
+    dev = torch.device("cuda", int(os.environ.get("MOC_BENCH_DEVICE", "0")) % n_dev if one_device else local_rank)
     torch.cuda.set_device(dev)
     cpus = granted_cpus()
     torch.set_num_threads(max(1, min(8, cpus // max(1, world))))   # the GPU leg's host side is serial
@@ -524,6 +525,7 @@ def main():
                "--classes", str(C), "--dim", str(D), "--topj", str(j), "--topk", str(K)] + (["--lognormal"] if a.lognormal else [])
         env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
         env["MOC_BENCH_ONE_DEVICE"] = "1"
+        env["MOC_BENCH_DEVICE"] = str(dev.index or 0)
         try:
             cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
             line = [ln for ln in cp.stdout.decode().splitlines() if ln.startswith("{")]
