@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 11
+#define MOC_ABI_VERSION 12
 
 enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
 
@@ -282,6 +282,24 @@ int moc_gated_attention_pool(const float* h, int64_t N, int L, const float* Wa, 
                              const float* Wb, const float* bb, int D, const float* Wc, const float* bc,
                              int K, float* A_raw, float* M, void* workspace, size_t workspace_bytes,
                              moc_stream_t stream);
+
+/* The backward of moc_gated_attention_pool (what autograd does behind Attn_Net_Gated.forward + softmax + mm:
+ * models/model_clam.py:58-63, :178-183, :206; the CLAM trainer calls loss.backward(), utils/core_utils.py:291).
+ * Given gA [K, N] (gradient at A_raw; nullable) and gM [K, L] (gradient at M; nullable; 16-byte aligned), one
+ * recompute pass over the bag (the forward's main loop, no activations were kept) writes
+ *   p   [K, N]        softmax_n(A_raw[k])
+ *   ds  [K, N]        total gradient at A_raw: p (dp - sum_n p dp) + gA with dp[k][n] = h[n] . gM[k]
+ *   dab [N, 2 D]      gradients at the two pre-activations h Wa^T + ba | h Wb^T + bb, side by side
+ *   dcol[(2 + K) D]   d_ba [D] | d_bb [D] | d_Wc [K, D]   (sums in a fixed order: deterministic)
+ * What remains are three plain GEMMs the caller hands to a library (rocBLAS / hipBLASLt: torch.mm):
+ *   [dWa; dWb] = dab^T h,    dh = dab [Wa; Wb] + p^T gM,    and  d_bc[k] = sum_n ds[k][n].
+ * Same shape limits as the forward; workspace: moc_gated_attention_backward_workspace bytes, 16-byte aligned. */
+size_t moc_gated_attention_backward_workspace(int64_t N, int L, int D, int K);
+int moc_gated_attention_backward(const float* h, int64_t N, int L, const float* Wa, const float* ba,
+                                 const float* Wb, const float* bb, int D, const float* Wc, int K,
+                                 const float* A_raw, const float* gA /*nullable*/, const float* gM /*nullable*/,
+                                 float* dab, float* p, float* ds, float* dcol, void* workspace,
+                                 size_t workspace_bytes, moc_stream_t stream);
 
 /* a10-a15 fused: `n` consecutive meta-steps (one slide each, slides slide0..slide0+n-1 in
  * order, one Adam step per slide: main_moc.py:380-410), parameters and Adam moments

@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 MOC_F32, MOC_BF16, MOC_F16 = 0, 1, 2
 SEL_BITS = {"topk": 1, "delta_softmax": 2, "delta_diff": 4, "bottomk": 8}
@@ -86,6 +86,9 @@ SIGNATURES = {
     "moc_gated_attention_workspace": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     "moc_gated_attention_pool": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p, _p, _p, C.c_int, _p, _p, C.c_int, _p, _p, _p,
                                            C.c_size_t, _p]),
+    "moc_gated_attention_backward_workspace": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "moc_gated_attention_backward": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p, _p, _p, C.c_int, _p, C.c_int, _p, _p, _p,
+                                               _p, _p, _p, _p, _p, C.c_size_t, _p]),
     "moc_topk_mean": (C.c_int, [_p, C.c_int64, _p, C.c_int64, _p, _p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, _p, _p, _p, _p]),
 }

@@ -23,6 +23,7 @@
 // dense -- N = 15,000, L = 512, D = 384: 70.8 GFLOP -> 28 us (the fp32 matrix pipe would need 75 us); the
 // bag is 30.7 MB (6 us of HBM time); each workgroup streams the 6 * D * L-byte weight image from L2 once.
 #include "moc_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -39,6 +40,16 @@ struct AttnArgs {
     const float *ba, *bb, *Wc, *bc;  // [D] [D] [K, D] [K]
     float* A_raw;                    // [K, N]
     float *ws_m, *ws_l, *ws_M;       // [G, K] [G, K] [G, K, L]
+    int64_t N;
+    int L, D, K;
+};
+struct AttnBwdArgs {                 // the recompute pass of the backward (kernel arguments live in scalar registers:
+    const float* h;                  // the forward keeps its own, shorter list)
+    const unsigned char* img;
+    const float *ba, *bb, *Wc;
+    const float* ds;                 // [K, N] gradient arriving at A_raw (through the softmax and directly)
+    float* dab;                      // [N, 2 D] gradients at the two pre-activations, (a | b) side by side
+    float* colpart;                  // [G][(2 + K) D] per-workgroup column sums: d_ba | d_bb | d_Wc[0..K)
     int64_t N;
     int L, D, K;
 };
@@ -155,8 +166,14 @@ __device__ __forceinline__ float gate_fn(float x, float y) {
 //     slab t, follow 6 CH instructions, so the barrier that ends slab t waits vmcnt(min(6 CH, 18)) first;
 //   * the tail re-fetches chunks and slabs nobody reads (wrapped indices): the counts stay the same to the end,
 //     and the final barrier drains them (vmcnt(0)) before the ring is reused by the epilogue.
-template <int ND>
-__global__ __launch_bounds__(256, 1) void gated_attention_kernel(AttnArgs a) {
+//
+// BWD = true is the recompute pass of the backward (moc_gated_attention_backward): the same main loop leaves the
+// pre-activations in the accumulators; the epilogue then turns them, in registers, into the gradients at the two
+// pre-activations -- dg = sum_k ds[k][n] Wc[k][d], da' = dg b (1 - a^2), db' = dg a b (1 - b) -- stores those
+// ([N, 2 D], the operand of the three plain GEMMs that remain: dWa | dWb = dab^T h, dh = dab [Wa; Wb]) and writes this
+// workgroup's column sums (d_ba, d_bb, d_Wc[k][d] = sum_n ds[k][n] a b) for a fixed-order merge.
+template <int ND, bool BWD>
+__global__ __launch_bounds__(256, 1) void gated_attention_kernel(std::conditional_t<BWD, AttnBwdArgs, AttnArgs> a) {
     constexpr int CH = ND / 4;                                        // chunks per slab = (a, b) tile pairs per wave
     static_assert(CH % 2 == 0, "the chunk loop alternates two register sets");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -302,6 +319,69 @@ __global__ __launch_bounds__(256, 1) void gated_attention_kernel(AttnArgs a) {
     at_barrier<0>();                                                  // the wrapped issues have landed: the ring is free
     MOC_STAMP(32);
 
+    if constexpr (BWD) {
+        // acc[c][s][r][i]: row r * 16 + (lane >> 4) * 4 + i, column (wave * CH + c) * 16 + (lane & 15)
+        float* ds_s = reinterpret_cast<float*>(smem);                 // [K][AT_ROWS], zero beyond the bag
+        for (int e = threadIdx.x; e < K * AT_ROWS; e += 256) {
+            const int k = e / AT_ROWS, r = e % AT_ROWS;
+            ds_s[e] = row0 + r < a.N ? a.ds[(int64_t)k * a.N + row0 + r] : 0.f;
+        }
+        __syncthreads();
+        const int col = lane & 15, D = a.D;
+        float* cp = a.colpart + (int64_t)blockIdx.x * (2 + K) * D;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int d = (wave * CH + c) * 16 + col;
+            float dg[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dg[r][i] = 0.f;
+            for (int k = 0; k < K; ++k) {                             // heads in order
+                const float w = a.Wc[(int64_t)k * D + d];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 v = *reinterpret_cast<const float4*>(ds_s + k * AT_ROWS + r * 16 + kq * 4);
+                    dg[r][0] = fmaf(v.x, w, dg[r][0]); dg[r][1] = fmaf(v.y, w, dg[r][1]);
+                    dg[r][2] = fmaf(v.z, w, dg[r][2]); dg[r][3] = fmaf(v.w, w, dg[r][3]);
+                }
+            }
+            float sa = 0.f, sb = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // tanh' = 4 e / (1 + e)^2 and sigmoid' = f / (1 + f)^2 in forms without cancellation
+                    const float e = __expf(2.f * fminf(fmaxf(acc[c][0][r][i], -15.f), 15.f));
+                    const float f = __expf(-fminf(fmaxf(acc[c][1][r][i], -30.f), 30.f));
+                    const float ie = __frcp_rn(1.f + e), bv = __frcp_rn(1.f + f);
+                    const float av = (e - 1.f) * ie, g = av * bv;
+                    const float da = dg[r][i] * bv * (4.f * e * ie * ie), db = dg[r][i] * g * (f * bv);
+                    acc[c][0][r][i] = g;                              // kept for d_Wc
+                    sa += da; sb += db;
+                    const int64_t row = row0 + r * 16 + kq * 4 + i;
+                    if (row < a.N) {
+                        a.dab[row * (2 * D) + d] = da;
+                        a.dab[row * (2 * D) + D + d] = db;
+                    }
+                }
+            sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+            sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+            if (kq == 0) { cp[d] = sa; cp[D + d] = sb; }
+            for (int k = 0; k < K; ++k) {
+                float sw = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 v = *reinterpret_cast<const float4*>(ds_s + k * AT_ROWS + r * 16 + kq * 4);
+                    sw = fmaf(v.x, acc[c][0][r][0], sw); sw = fmaf(v.y, acc[c][0][r][1], sw);
+                    sw = fmaf(v.z, acc[c][0][r][2], sw); sw = fmaf(v.w, acc[c][0][r][3], sw);
+                }
+                sw += __shfl_xor(sw, 16, 64); sw += __shfl_xor(sw, 32, 64);
+                if (kq == 0) cp[(int64_t)(2 + k) * D + d] = sw;
+            }
+        }
+    } else {
+
     // ---- gate and scores.  acc[c][s][r][i]: row r * 16 + (lane >> 4) * 4 + i, column (wave * CH + c) * 16 + (lane & 15)
     float* part_s = reinterpret_cast<float*>(smem);                  // [4 waves][K][AT_ROWS]
     float* score_s = part_s + (size_t)4 * K * AT_ROWS;                // [K][AT_ROWS]
@@ -444,6 +524,7 @@ __global__ __launch_bounds__(256, 1) void gated_attention_kernel(AttnArgs a) {
         __syncthreads();
     }
     MOC_STAMP(34);
+    }
 }
 
 // grid (K, ceil(L / 16)): merge the G per-workgroup triples of head k for 16 columns.  Thread = (column, one
@@ -499,11 +580,111 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const float* ws_m,
     }
 }
 
+// ---- backward helpers -----------------------------------------------------------------------------------------
+// dp[k][n] = h[n] . gM[k] (the gradient arriving at softmax weight p[k][n] through M = p h).  One wave per row at a
+// time, lanes along the row (float4), butterfly sum in a fixed order.
+__global__ __launch_bounds__(256) void attn_bwd_dp_kernel(const float* h, const float* gM, int64_t N, int L, int K, float* dp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    const int L4 = L / 4;
+    for (int64_t n = wave; n < N; n += nw) {
+        const float4* hr = reinterpret_cast<const float4*>(h + n * L);
+        for (int k = 0; k < K; ++k) {
+            const float4* gr = reinterpret_cast<const float4*>(gM + (int64_t)k * L);
+            float s = 0.f;
+            for (int c = lane; c < L4; c += 64) {
+                const float4 x = hr[c], g = gr[c];
+                s = fmaf(x.x, g.x, s); s = fmaf(x.y, g.y, s); s = fmaf(x.z, g.z, s); s = fmaf(x.w, g.w, s);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (lane == 0) dp[(int64_t)k * N + n] = s;
+        }
+    }
+}
+
+__device__ __forceinline__ float attn_block_reduce(float v, float* red, bool is_max) {      // 1024 threads, fixed order
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] = is_max ? fmaxf(red[threadIdx.x], red[threadIdx.x + st]) : red[threadIdx.x] + red[threadIdx.x + st];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// grid K, one workgroup per head: p = softmax_n(A_raw[k]);  ds = p (dp - sum_n p dp) + gA  -- the gradient at A_raw
+// from M (through the softmax; dp null: none) plus the one arriving at A_raw itself (gA null: none).
+__global__ __launch_bounds__(1024) void attn_bwd_ds_kernel(const float* A_raw, const float* dp, const float* gA, int64_t N,
+                                                           float* p, float* ds) {
+    __shared__ float red[1024];
+    const int64_t base = (int64_t)blockIdx.x * N;
+    float m = -INFINITY;
+    for (int64_t n = threadIdx.x; n < N; n += 1024) m = fmaxf(m, A_raw[base + n]);
+    m = attn_block_reduce(m, red, true);
+    float l = 0.f, c = 0.f;
+    for (int64_t n = threadIdx.x; n < N; n += 1024) {
+        const float e = expf(A_raw[base + n] - m);
+        l += e;
+        if (dp) c = fmaf(e, dp[base + n], c);
+    }
+    l = attn_block_reduce(l, red, false);
+    c = attn_block_reduce(c, red, false) / l;
+    for (int64_t n = threadIdx.x; n < N; n += 1024) {
+        const float pr = expf(A_raw[base + n] - m) / l;
+        p[base + n] = pr;
+        ds[base + n] = (dp ? pr * (dp[base + n] - c) : 0.f) + (gA ? gA[base + n] : 0.f);
+    }
+}
+
+// column sums of the per-workgroup parts, workgroups in order: out[j] = sum_g part[g][j]
+__global__ __launch_bounds__(256) void attn_bwd_colsum_kernel(const float* part, int G, int W, float* out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= W) return;
+    float s = 0.f;
+    int g = 0;
+    for (; g + 4 <= G; g += 4) {
+        const float v0 = part[(int64_t)g * W + j], v1 = part[(int64_t)(g + 1) * W + j];
+        const float v2 = part[(int64_t)(g + 2) * W + j], v3 = part[(int64_t)(g + 3) * W + j];
+        s = ((s + v0) + v1) + v2 + v3;
+    }
+    for (; g < G; ++g) s += part[(int64_t)g * W + j];
+    out[j] = s;
+}
+
 size_t attn_image_floats(int L, int D) { return (size_t)((L + 31) / 32) * D * 96; }      // 6 bytes per (padded) weight x 2 projections
 
 size_t attn_ws_floats(int64_t N, int L, int D, int K) {
     const int64_t G = (N + AT_ROWS - 1) / AT_ROWS;
     return attn_image_floats(L, D) + (size_t)G * K * 2 + (size_t)G * K * L;
+}
+
+size_t attn_bwd_ws_floats(int64_t N, int L, int D, int K) {
+    const int64_t G = (N + AT_ROWS - 1) / AT_ROWS;
+    return attn_image_floats(L, D) + (size_t)G * (2 + K) * D + (size_t)K * N;
+}
+
+template <bool BWD>
+int attn_launch(const std::conditional_t<BWD, AttnBwdArgs, AttnArgs>& a, int G, hipStream_t s, const char* what) {
+#define MOC_LAUNCH_ATTN(NDV)                                                                                         \
+    do {                                                                                                             \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            const hipError_t ea = hipFuncSetAttribute((const void*)gated_attention_kernel<NDV, BWD>,                 \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, AT_SMEM);          \
+            if (ea != hipSuccess) MOC_FAIL(MOC_ELAUNCH, "%s: %s", what, hipGetErrorString(ea));                      \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        gated_attention_kernel<NDV, BWD><<<G, 256, AT_SMEM, s>>>(a);                                                 \
+    } while (0)
+    if (a.D == 128) MOC_LAUNCH_ATTN(8);
+    else if (a.D == 256) MOC_LAUNCH_ATTN(16);
+    else MOC_LAUNCH_ATTN(24);
+#undef MOC_LAUNCH_ATTN
+    MOC_CHECK_LAUNCH(what);
+    return MOC_OK;
 }
 
 }  // namespace
@@ -539,23 +720,54 @@ extern "C" int moc_gated_attention_pool(const float* h, int64_t N, int L, const 
     attn_image_kernel<<<moc_cdiv(nfrag, 256), 256, 0, s>>>(Wa, Wb, L, D, (uint4*)img);
     MOC_CHECK_LAUNCH("moc_gated_attention_pool(image)");
     static_assert((size_t)(5 * 64 + 1) * AT_ROWS * sizeof(float) + 4096 <= AT_SMEM, "the epilogue arrays (K <= 64) reuse the ring");
-#define MOC_LAUNCH_ATTN(NDV)                                                                                         \
-    do {                                                                                                             \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
-            const hipError_t ea = hipFuncSetAttribute((const void*)gated_attention_kernel<NDV>,                      \
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, AT_SMEM);          \
-            if (ea != hipSuccess) MOC_FAIL(MOC_ELAUNCH, "moc_gated_attention_pool: %s", hipGetErrorString(ea));      \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
-        gated_attention_kernel<NDV><<<G, 256, AT_SMEM, s>>>(a);                                                      \
-    } while (0)
-    if (D == 128) MOC_LAUNCH_ATTN(8);
-    else if (D == 256) MOC_LAUNCH_ATTN(16);
-    else MOC_LAUNCH_ATTN(24);
-#undef MOC_LAUNCH_ATTN
-    MOC_CHECK_LAUNCH("moc_gated_attention_pool");
+    { const int rc = attn_launch<false>(a, G, s, "moc_gated_attention_pool"); if (rc != MOC_OK) return rc; }
     attention_merge_kernel<<<dim3(K, moc_cdiv(L, 16)), 256, (size_t)G * sizeof(float), s>>>(a.ws_m, a.ws_l, a.ws_M, G, K, L, M);
     MOC_CHECK_LAUNCH("moc_gated_attention_pool(merge)");
+    return MOC_OK;
+}
+
+extern "C" size_t moc_gated_attention_backward_workspace(int64_t N, int L, int D, int K) {
+    if (N < 1 || L < 16 || D < 16 || K < 1) return 0;
+    return attn_bwd_ws_floats(N, L, D, K) * sizeof(float);
+}
+
+extern "C" int moc_gated_attention_backward(const float* h, int64_t N, int L, const float* Wa, const float* ba,
+                                            const float* Wb, const float* bb, int D, const float* Wc, int K,
+                                            const float* A_raw, const float* gA, const float* gM, float* dab, float* p,
+                                            float* ds, float* dcol, void* workspace, size_t workspace_bytes,
+                                            moc_stream_t stream) {
+    MOC_REQUIRE(h && Wa && ba && Wb && bb && Wc && A_raw && dab && p && ds && dcol && workspace,
+                "moc_gated_attention_backward: null pointer");
+    MOC_REQUIRE(N >= 1 && N < (1ll << 31), "moc_gated_attention_backward: bad N=%lld", (long long)N);
+    MOC_REQUIRE(L >= 16 && L % 16 == 0 && L <= 4096, "moc_gated_attention_backward: L=%d must be a multiple of 16 (<= 4096)", L);
+    MOC_REQUIRE(D == 128 || D == 256 || D == 384, "moc_gated_attention_backward: D=%d not in {128, 256, 384}", D);
+    MOC_REQUIRE(K >= 1 && K <= 64, "moc_gated_attention_backward: K=%d outside [1, 64]", K);
+    MOC_REQUIRE(((uintptr_t)h & 15) == 0 && ((uintptr_t)Wa & 15) == 0 && ((uintptr_t)Wb & 15) == 0 &&
+                ((uintptr_t)workspace & 15) == 0 && (!gM || ((uintptr_t)gM & 15) == 0),
+                "moc_gated_attention_backward: h, Wa, Wb, gM and the workspace must be 16-byte aligned");
+    MOC_REQUIRE(workspace_bytes >= attn_bwd_ws_floats(N, L, D, K) * sizeof(float),
+                "moc_gated_attention_backward: workspace of %zu bytes, need %zu", workspace_bytes, attn_bwd_ws_floats(N, L, D, K) * sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    const int G = (int)((N + AT_ROWS - 1) / AT_ROWS);
+    float* img = (float*)workspace;
+    float* colpart = img + attn_image_floats(L, D);
+    float* dp = colpart + (size_t)G * (2 + K) * D;
+    const int64_t nfrag = (int64_t)((L + 31) / 32) * 4 * (D / 64) * 2 * 64;
+    attn_image_kernel<<<moc_cdiv(nfrag, 256), 256, 0, s>>>(Wa, Wb, L, D, (uint4*)img);
+    MOC_CHECK_LAUNCH("moc_gated_attention_backward(image)");
+    if (gM) {
+        attn_bwd_dp_kernel<<<(int)(G < 1024 ? G : 1024), 256, 0, s>>>(h, gM, N, L, K, dp);
+        MOC_CHECK_LAUNCH("moc_gated_attention_backward(dp)");
+    }
+    attn_bwd_ds_kernel<<<K, 1024, 0, s>>>(A_raw, gM ? dp : nullptr, gA, N, p, ds);
+    MOC_CHECK_LAUNCH("moc_gated_attention_backward(ds)");
+    AttnBwdArgs a{};
+    a.h = h; a.img = (const unsigned char*)img; a.ba = ba; a.bb = bb; a.Wc = Wc;
+    a.ds = ds; a.dab = dab; a.colpart = colpart;
+    a.N = N; a.L = L; a.D = D; a.K = K;
+    { const int rc = attn_launch<true>(a, G, s, "moc_gated_attention_backward"); if (rc != MOC_OK) return rc; }
+    const int W = (2 + K) * D;
+    attn_bwd_colsum_kernel<<<moc_cdiv(W, 256), 256, 0, s>>>(colpart, G, W, dcol);
+    MOC_CHECK_LAUNCH("moc_gated_attention_backward(colsum)");
     return MOC_OK;
 }

@@ -6,8 +6,10 @@ What makes these models is the aggregation over the N patches -- attention score
 gate, softmax over N, attention-weighted sum of the patch features.  That whole step is ONE pass over
 the bag on the HIP path (moc_gated_attention_pool: fp32 MFMA projections, gate and scores in registers,
 online softmax; engine.gated_attention_pool); the layers around it (the first fc, the bag and instance
-classifiers) are plain torch GEMMs.  The backward pass re-derives the step with torch operations from
-the saved inputs (the forward keeps neither the [N, D] activations nor the softmax).
+classifiers) are plain torch GEMMs.  The backward pass is HIP as well (moc_gated_attention_backward): the forward keeps
+neither the [N, D] activations nor the softmax, so one recompute pass (the forward's main loop) turns the arriving
+gradients into those at the two pre-activations, with the gate's derivative taken in registers, and only three plain
+GEMMs (dW = dab^T h, dh = dab [Wa; Wb]) go to the library.
 
 The un-gated network (`gate=False`, Attn_Net: A = Wc tanh(Wa h + ba) + bc) runs through the same kernel with a gate
 that is exactly one: Wb = 0 and bb = 40 give sigmoid(40) = 1 - 4e-18, which IS 1.0f in fp32 (and 1 + e^-40 == 1.0f in
@@ -35,32 +37,23 @@ def initialize_weights(module):
             nn.init.constant_(m.bias, 0)
 
 
-def _gate_scores_torch(h, Wa, ba, Wb, bb, Wc, bc):
-    a = torch.tanh(F.linear(h, Wa, ba))
-    b = torch.sigmoid(F.linear(h, Wb, bb))
-    return F.linear(a * b, Wc, bc).t()                       # [K, N]
-
-
 class _GatedAttentionPool(torch.autograd.Function):
+    """Forward and backward both in HIP: the backward recomputes the gate in one pass over the bag (nothing but A_raw
+    was kept) and leaves three plain GEMMs to the library (engine.gated_attention_backward)."""
+
     @staticmethod
     def forward(ctx, h, Wa, ba, Wb, bb, Wc, bc):
         A_raw, M = engine.gated_attention_pool(h, Wa, ba, Wb, bb, Wc, bc)
-        ctx.save_for_backward(h, Wa, ba, Wb, bb, Wc, bc)
+        ctx.save_for_backward(h, Wa, ba, Wb, bb, Wc, A_raw)
         return A_raw, M
 
     @staticmethod
     def backward(ctx, gA, gM):
-        saved = [t.detach().requires_grad_(True) for t in ctx.saved_tensors]
-        with torch.enable_grad():
-            A = _gate_scores_torch(*saved)
-            M = torch.softmax(A, dim=1) @ saved[0]
-            outs, grads = [], []
-            if gA is not None:
-                outs.append(A); grads.append(gA)
-            if gM is not None:
-                outs.append(M); grads.append(gM)
-            res = torch.autograd.grad(outs, saved, grads, allow_unused=True)
-        return tuple(res)
+        h, Wa, ba, Wb, bb, Wc, A_raw = ctx.saved_tensors
+        if gA is None and gM is None:
+            return (None,) * 7
+        res = engine.gated_attention_backward(h, Wa, ba, Wb, bb, Wc, A_raw, gA, gM)
+        return tuple(r if need else None for r, need in zip(res, ctx.needs_input_grad))
 
 
 def gated_attention_pool(h, Wa, ba, Wb, bb, Wc, bc):

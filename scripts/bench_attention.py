@@ -58,6 +58,18 @@ def main():
 
     us = timed(lambda: engine.gated_attention_pool(*gpu), a.iters)
     us_t = timed(lambda: torch_step(*gpu), a.iters)
+    # forward + backward (gradient arriving at A_raw and at M, every input's gradient asked for)
+    from moc_amd.model_clam import gated_attention_pool
+    uA, uM = torch.randn(a.k, a.n, device=dev), torch.randn(a.k, a.l, device=dev)
+
+    def fb(fn):
+        ins = [t.detach().requires_grad_(True) for t in gpu]
+        A, M = fn(*ins)
+        torch.autograd.grad([A, M], ins, [uA, uM])
+
+    us_fb, us_fb_t = timed(lambda: fb(gated_attention_pool), a.iters), timed(lambda: fb(torch_step), a.iters)
+    A_saved = engine.gated_attention_pool(*gpu)[0]
+    us_b = timed(lambda: engine.gated_attention_backward(*gpu[:6], A_saved, uA, uM), a.iters)
     t0 = time.perf_counter()
     reps = 3
     for _ in range(reps):
@@ -67,6 +79,8 @@ def main():
     print(f"  moc_gated_attention_pool : {us:8.1f} us  {flops / us / 1e6:6.1f} TFLOP/s fp32-exact = {6 * flops / us / 1e6:6.1f} TFLOP/s of bf16 products "
           f"({6 * flops / us / 1e6 / (BF16_MFMA_PEAK / 1e12):.2f} of the bf16 matrix peak; {flops / us / 1e6 / (F32_MFMA_PEAK / 1e12):.2f} x the fp32 matrix peak)")
     print(f"  torch on the same GPU    : {us_t:8.1f} us  (5 library kernels, [N, D] activations through HBM)")
+    print(f"  forward + backward       : {us_fb:8.1f} us  (moc_gated_attention_backward alone, with its three library GEMMs: {us_b:.1f} us); "
+          f"torch autograd on the same GPU {us_fb_t:.1f} us")
     print(f"  torch on the host cores  : {cpu_us:8.1f} us  ({torch.get_num_threads()} threads)")
 
 

@@ -87,6 +87,56 @@ def test_gated_attention_pool_survives_large_scores(gpu_device):
     np.testing.assert_allclose(M.cpu().numpy(), M_ref.float().numpy(), atol=5e-3, rtol=0)
 
 
+@pytest.mark.parametrize("N,L,D,K,use", [(1, 512, 256, 1, "AM"), (63, 512, 256, 1, "AM"), (64, 512, 384, 3, "AM"),
+                                         (1000, 512, 384, 1, "M"), (1000, 512, 384, 2, "A"), (4097, 1024, 128, 2, "AM"),
+                                         (15000, 512, 384, 1, "AM"), (777, 64, 256, 5, "AM"), (65, 48, 128, 33, "AM"),
+                                         (300, 512, 256, 64, "AM")])
+def test_gated_attention_backward_matches_float64_autograd(gpu_device, N, L, D, K, use):
+    """moc_gated_attention_backward (through the autograd Function the models use) against autograd on the float64
+    restatement: every input's gradient, with the gradient arriving at A_raw, at M, or both.  Tolerance 1e-4 of each
+    gradient's largest magnitude (fp32 sums over up to 15,000 rows; floor 1e-2: d_bc is exactly zero when only M is
+    used -- the softmax does not see a shift -- and arrives as the rounding of a cancelling sum)."""
+    from moc_amd.model_clam import gated_attention_pool
+    from oracle import baselines_oracle as BO
+    g = lambda s, *shape: HB.randn(s, *shape)
+    h = torch.relu(g(1, N, L))
+    ops = [h, g(2, D, L) * (2.0 / (L + D)) ** 0.5, g(4, D) * 0.1, g(3, D, L) * (2.0 / (L + D)) ** 0.5, g(5, D) * 0.1,
+           g(6, K, D) * (2.0 / (D + K)) ** 0.5 * 3.0, g(7, K) * 0.1]
+    uA, uM = g(8, K, N), g(9, K, L)
+    ref_in = [t.double().requires_grad_(True) for t in ops]
+    A_ref, M_ref = BO.gated_attention_pool(*ref_in)
+    loss = (A_ref * uA.double()).sum() * ("A" in use) + (M_ref * uM.double()).sum() * ("M" in use)
+    ref = torch.autograd.grad(loss, ref_in)
+    dev = torch.device("cuda:0")
+    got_in = [t.to(dev).requires_grad_(True) for t in ops]
+    A, M = gated_attention_pool(*got_in)
+    loss = (A * uA.to(dev)).sum() * ("A" in use) + (M * uM.to(dev)).sum() * ("M" in use)
+    got = torch.autograd.grad(loss, got_in)
+    for name, a, b in zip(["h", "Wa", "ba", "Wb", "bb", "Wc", "bc"], got, ref):
+        scale = max(float(b.abs().max()), 1e-2)
+        err = float((a.double().cpu() - b).abs().max()) / scale
+        assert err < 1e-4, f"d{name}: {err:.3e} of its scale {scale:.3e}"
+
+
+def test_gated_attention_backward_is_deterministic_and_skips_unneeded(gpu_device):
+    """Fixed-order sums: two runs give the same bits; inputs that need no gradient get None (the un-gated network's
+    constant gate operands)."""
+    from moc_amd.model_clam import gated_attention_pool
+    dev = torch.device("cuda:0")
+    N, L, D, K = 5000, 512, 256, 2
+    ops = [torch.relu(HB.randn(1, N, L)), HB.randn(2, D, L) * 0.05, HB.randn(3, D) * 0.1, torch.zeros(D, L), torch.full((D,), 40.0),
+           HB.randn(4, K, D) * 0.2, HB.randn(5, K) * 0.1]
+    runs = []
+    for _ in range(2):
+        ins = [t.to(dev).requires_grad_(i not in (3, 4)) for i, t in enumerate(ops)]
+        A, M = gated_attention_pool(*ins)
+        (A.sum() + (M * M).sum()).backward()
+        assert ins[3].grad is None and ins[4].grad is None
+        runs.append([t.grad.clone() for i, t in enumerate(ins) if i not in (3, 4)])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("i", range(len(HB.CLAM_CASES)), ids=[c[0] for c in HB.CLAM_CASES])
 def test_clam_models_on_the_hip_path(gpu_device, i):
     from test_baselines_cpu import check_clam, run_clam
@@ -104,7 +154,7 @@ def test_clam_models_on_the_hip_path(gpu_device, i):
 @pytest.mark.parametrize("case", HB.CLAM_HOOK_CASES, ids=[c[0] for c in HB.CLAM_HOOK_CASES])
 def test_clam_trainer_hooks_on_the_hip_path(gpu_device, case, tmp_path):
     """train_loop_clam / validate_clam / summary driving CLAM_SB / CLAM_MB on the GPU (attention through
-    moc_gated_attention_pool, forward and -- by recomputation -- backward) against the reference's own run."""
+    moc_gated_attention_pool / moc_gated_attention_backward) against the reference's own run."""
     import moc_amd.core_utils as core
     import moc_amd.model_clam as Mc
     from test_baselines_cpu import check_clam_hooks
