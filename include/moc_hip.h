@@ -286,19 +286,23 @@ int moc_gated_attention_pool(const float* h, int64_t N, int L, const float* Wa, 
 /* The backward of moc_gated_attention_pool (what autograd does behind Attn_Net_Gated.forward + softmax + mm:
  * models/model_clam.py:58-63, :178-183, :206; the CLAM trainer calls loss.backward(), utils/core_utils.py:291).
  * Given gA [K, N] (gradient at A_raw; nullable) and gM [K, L] (gradient at M; nullable; 16-byte aligned), one
- * recompute pass over the bag (the forward's main loop, no activations were kept) writes
- *   p   [K, N]        softmax_n(A_raw[k])
+ * recompute pass over the bag (the forward's main loop: no activations were kept) writes
+ *   dab [N, S]        S = moc_gated_attention_dab_stride(D, K) = 2 D + 16 ceil(K / 16): columns [0, D) and [D, 2 D)
+ *                     the gradients at the two pre-activations h Wa^T + ba | h Wb^T + bb; column 2 D + k the
+ *                     softmax p[k][n] = softmax_n(A_raw[k]); the rest zero
  *   ds  [K, N]        total gradient at A_raw: p (dp - sum_n p dp) + gA with dp[k][n] = h[n] . gM[k]
- *   dab [N, 2 D]      gradients at the two pre-activations h Wa^T + ba | h Wb^T + bb, side by side
- *   dcol[(2 + K) D]   d_ba [D] | d_bb [D] | d_Wc [K, D]   (sums in a fixed order: deterministic)
- * What remains are three plain GEMMs the caller hands to a library (rocBLAS / hipBLASLt: torch.mm):
- *   [dWa; dWb] = dab^T h,    dh = dab [Wa; Wb] + p^T gM,    and  d_bc[k] = sum_n ds[k][n].
+ *   dcol[(2 + K) D]   d_ba [D] | d_bb [D] | d_Wc [K, D]
+ *   dbc [K]           d_bc
+ * (every sum in a fixed order: deterministic).  What remains are two plain GEMMs the caller hands to a library
+ * (rocBLAS / hipBLASLt: torch.mm) over X = [Wa; Wb; gM; 0] ([S, L]; zeros for gM when it is null):
+ *   dh = dab X      and      dab^T h = [dWa; dWb; (M, unused)].
  * Same shape limits as the forward; workspace: moc_gated_attention_backward_workspace bytes, 16-byte aligned. */
 size_t moc_gated_attention_backward_workspace(int64_t N, int L, int D, int K);
+int moc_gated_attention_dab_stride(int D, int K);
 int moc_gated_attention_backward(const float* h, int64_t N, int L, const float* Wa, const float* ba,
                                  const float* Wb, const float* bb, int D, const float* Wc, int K,
                                  const float* A_raw, const float* gA /*nullable*/, const float* gM /*nullable*/,
-                                 float* dab, float* p, float* ds, float* dcol, void* workspace,
+                                 float* dab, float* ds, float* dcol, float* dbc, void* workspace,
                                  size_t workspace_bytes, moc_stream_t stream);
 
 /* a10-a15 fused: `n` consecutive meta-steps (one slide each, slides slide0..slide0+n-1 in

@@ -87,6 +87,7 @@ SIGNATURES = {
     "moc_gated_attention_pool": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p, _p, _p, C.c_int, _p, _p, C.c_int, _p, _p, _p,
                                            C.c_size_t, _p]),
     "moc_gated_attention_backward_workspace": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "moc_gated_attention_dab_stride": (C.c_int, [C.c_int, C.c_int]),
     "moc_gated_attention_backward": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p, _p, _p, C.c_int, _p, C.c_int, _p, _p, _p,
                                                _p, _p, _p, _p, _p, C.c_size_t, _p]),
     "moc_topk_mean": (C.c_int, [_p, C.c_int64, _p, C.c_int64, _p, _p, C.c_int, C.c_int, C.c_int,

@@ -43,12 +43,14 @@ struct AttnArgs {
     int64_t N;
     int L, D, K;
 };
+// row stride of the backward's `dab`: the two gradients, then the K softmax columns, padded to 16 floats
+__host__ __device__ constexpr int attn_dab_stride(int D, int K) { return 2 * D + 16 * ((K + 15) / 16); }
 struct AttnBwdArgs {                 // the recompute pass of the backward (kernel arguments live in scalar registers:
     const float* h;                  // the forward keeps its own, shorter list)
     const unsigned char* img;
     const float *ba, *bb, *Wc;
     const float* ds;                 // [K, N] gradient arriving at A_raw (through the softmax and directly)
-    float* dab;                      // [N, 2 D] gradients at the two pre-activations, (a | b) side by side
+    float* dab;                      // [N, attn_dab_stride] gradients at the two pre-activations, (a | b) side by side
     float* colpart;                  // [G][(2 + K) D] per-workgroup column sums: d_ba | d_bb | d_Wc[0..K)
     int64_t N;
     int L, D, K;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void gated_attention_kernel(std::conditiona
             ds_s[e] = row0 + r < a.N ? a.ds[(int64_t)k * a.N + row0 + r] : 0.f;
         }
         __syncthreads();
-        const int col = lane & 15, D = a.D;
+        const int col = lane & 15, D = a.D, S = attn_dab_stride(D, K);
         float* cp = a.colpart + (int64_t)blockIdx.x * (2 + K) * D;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -361,8 +363,8 @@ __global__ __launch_bounds__(256, 1) void gated_attention_kernel(std::conditiona
                     sa += da; sb += db;
                     const int64_t row = row0 + r * 16 + kq * 4 + i;
                     if (row < a.N) {
-                        a.dab[row * (2 * D) + d] = da;
-                        a.dab[row * (2 * D) + D + d] = db;
+                        a.dab[row * S + d] = da;
+                        a.dab[row * S + D + d] = db;
                     }
                 }
             sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
@@ -581,77 +583,133 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const float* ws_m,
 }
 
 // ---- backward helpers -----------------------------------------------------------------------------------------
-// dp[k][n] = h[n] . gM[k] (the gradient arriving at softmax weight p[k][n] through M = p h).  One wave per row at a
-// time, lanes along the row (float4), butterfly sum in a fixed order.
-__global__ __launch_bounds__(256) void attn_bwd_dp_kernel(const float* h, const float* gM, int64_t N, int L, int K, float* dp) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
-    const int L4 = L / 4;
-    for (int64_t n = wave; n < N; n += nw) {
-        const float4* hr = reinterpret_cast<const float4*>(h + n * L);
-        for (int k = 0; k < K; ++k) {
-            const float4* gr = reinterpret_cast<const float4*>(gM + (int64_t)k * L);
-            float s = 0.f;
-            for (int c = lane; c < L4; c += 64) {
-                const float4 x = hr[c], g = gr[c];
-                s = fmaf(x.x, g.x, s); s = fmaf(x.y, g.y, s); s = fmaf(x.z, g.z, s); s = fmaf(x.w, g.w, s);
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-            if (lane == 0) dp[(int64_t)k * N + n] = s;
-        }
-    }
-}
 
-__device__ __forceinline__ float attn_block_reduce(float v, float* red, bool is_max) {      // 1024 threads, fixed order
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int st = 512; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) red[threadIdx.x] = is_max ? fmaxf(red[threadIdx.x], red[threadIdx.x + st]) : red[threadIdx.x] + red[threadIdx.x + st];
+// grid G (64 rows per workgroup, as the main kernel).  dp[k][n] = h[n] . gM[k] -- the gradient arriving at the softmax
+// weight p[k][n] through M = p h -- wave w on rows 16 w .. 16 w + 15, four rows in flight, lanes along the row (float4),
+// butterfly sums in a fixed order.  Then the workgroup's share of the softmax statistics of every head, online form:
+// part[g][k] = (m, l = sum e, c = sum e dp, sum gA) with e = exp(A_raw - m) over its rows.
+__global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const float* h, const float* gM, const float* A_raw, const float* gA,
+                                                            int64_t N, int L, int K, float* dp, float4* part) {
+    __shared__ float dp_s[AT_ROWS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * AT_ROWS;
+    const int nrow = N - row0 < AT_ROWS ? (int)(N - row0) : AT_ROWS;
+    const int L4 = L / 4;
+    for (int k = 0; k < K; ++k) {
+        if (gM) {
+            const float4* gr = reinterpret_cast<const float4*>(gM + (int64_t)k * L);
+            for (int r = wave * 16; r < wave * 16 + 16; r += 4) {
+                float s[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int c = lane; c < L4; c += 64) {
+                    const float4 g = gr[c];
+                    float4 x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int rr = r + u < nrow ? r + u : nrow - 1;                  // clamp: loads stay in the bag
+                        x[u] = reinterpret_cast<const float4*>(h + (row0 + rr) * L)[c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        s[u] = fmaf(x[u].x, g.x, s[u]); s[u] = fmaf(x[u].y, g.y, s[u]);
+                        s[u] = fmaf(x[u].z, g.z, s[u]); s[u] = fmaf(x[u].w, g.w, s[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) s[u] += __shfl_xor(s[u], off, 64);
+                }
+                if (lane < 4) {
+                    const float v = lane == 0 ? s[0] : lane == 1 ? s[1] : lane == 2 ? s[2] : s[3];
+                    dp_s[r + lane] = v;
+                    if (r + lane < nrow) dp[(int64_t)k * N + row0 + r + lane] = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {                                              // one lane per row
+            const bool valid = lane < nrow;
+            const float sc = valid ? A_raw[(int64_t)k * N + row0 + lane] : -INFINITY;
+            float m = sc;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            const float e = valid ? expf(sc - m) : 0.f;
+            float l = e, c = gM && valid ? e * dp_s[lane] : 0.f, sg = gA && valid ? gA[(int64_t)k * N + row0 + lane] : 0.f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                l += __shfl_xor(l, off, 64); c += __shfl_xor(c, off, 64); sg += __shfl_xor(sg, off, 64);
+            }
+            if (lane == 0) part[(int64_t)blockIdx.x * K + k] = float4{m, l, c, sg};
+        }
         __syncthreads();
     }
-    const float r = red[0];
-    __syncthreads();
-    return r;
 }
 
-// grid K, one workgroup per head: p = softmax_n(A_raw[k]);  ds = p (dp - sum_n p dp) + gA  -- the gradient at A_raw
-// from M (through the softmax; dp null: none) plus the one arriving at A_raw itself (gA null: none).
-__global__ __launch_bounds__(1024) void attn_bwd_ds_kernel(const float* A_raw, const float* dp, const float* gA, int64_t N,
-                                                           float* p, float* ds) {
-    __shared__ float red[1024];
-    const int64_t base = (int64_t)blockIdx.x * N;
+// grid (ceil(N / 256), K).  Every workgroup merges the G parts of its head in the same fixed order (thread t takes
+// parts t, t + 256, ...; tree over the threads), then, for its 256 rows:  p = softmax_n(A_raw[k]),
+// ds = p (dp - sum_n p dp) + gA  -- the gradient at A_raw from M through the softmax (dp null: none) plus the one
+// arriving at A_raw itself (gA null: none).  p goes to column 2 D + k of dab (the columns up to the stride are zeroed: the
+// caller's GEMMs run over the whole stride).  d_bc[k] = sum_n gA[k][n]: the softmax term sums to zero over n.
+__global__ __launch_bounds__(256) void attn_bwd_ds_kernel(const float* A_raw, const float* dp, const float* gA, const float4* part,
+                                                          int64_t N, int G, int D, int K, float* dab, float* ds, float* dbc) {
+    __shared__ float red[256];
+    const int k = blockIdx.y, S = attn_dab_stride(D, K);
+    auto reduce = [&](float v, bool is_max) {
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] = is_max ? fmaxf(red[threadIdx.x], red[threadIdx.x + st]) : red[threadIdx.x] + red[threadIdx.x + st];
+            __syncthreads();
+        }
+        const float r = red[0];
+        __syncthreads();
+        return r;
+    };
     float m = -INFINITY;
-    for (int64_t n = threadIdx.x; n < N; n += 1024) m = fmaxf(m, A_raw[base + n]);
-    m = attn_block_reduce(m, red, true);
-    float l = 0.f, c = 0.f;
-    for (int64_t n = threadIdx.x; n < N; n += 1024) {
-        const float e = expf(A_raw[base + n] - m);
-        l += e;
-        if (dp) c = fmaf(e, dp[base + n], c);
+    for (int g = threadIdx.x; g < G; g += 256) m = fmaxf(m, part[(int64_t)g * K + k].x);
+    m = reduce(m, true);
+    float l = 0.f, c = 0.f, sg = 0.f;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        const float4 q = part[(int64_t)g * K + k];
+        const float sc = expf(q.x - m);
+        l = fmaf(sc, q.y, l); c = fmaf(sc, q.z, c); sg += q.w;
     }
-    l = attn_block_reduce(l, red, false);
-    c = attn_block_reduce(c, red, false) / l;
-    for (int64_t n = threadIdx.x; n < N; n += 1024) {
-        const float pr = expf(A_raw[base + n] - m) / l;
-        p[base + n] = pr;
-        ds[base + n] = (dp ? pr * (dp[base + n] - c) : 0.f) + (gA ? gA[base + n] : 0.f);
-    }
+    l = reduce(l, false);
+    c = reduce(c, false) / l;
+    sg = reduce(sg, false);
+    if (blockIdx.x == 0 && threadIdx.x == 0) dbc[k] = sg;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float pr = expf(A_raw[(int64_t)k * N + n] - m) / l;
+    ds[(int64_t)k * N + n] = (dp ? pr * (dp[(int64_t)k * N + n] - c) : 0.f) + (gA ? gA[(int64_t)k * N + n] : 0.f);
+    dab[n * S + 2 * D + k] = pr;
+    if (k == 0)
+        for (int j = 2 * D + K; j < S; ++j) dab[n * S + j] = 0.f;
 }
 
-// column sums of the per-workgroup parts, workgroups in order: out[j] = sum_g part[g][j]
+// column sums of the per-workgroup parts, workgroups in a fixed order: out[j] = sum_g part[g][j].  Thread = (column,
+// one of sixteen interleaved slices of the workgroups); the sixteen partial sums meet in LDS.
 __global__ __launch_bounds__(256) void attn_bwd_colsum_kernel(const float* part, int G, int W, float* out) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= W) return;
+    __shared__ float red[256];
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15), slice = threadIdx.x >> 4;
     float s = 0.f;
-    int g = 0;
-    for (; g + 4 <= G; g += 4) {
-        const float v0 = part[(int64_t)g * W + j], v1 = part[(int64_t)(g + 1) * W + j];
-        const float v2 = part[(int64_t)(g + 2) * W + j], v3 = part[(int64_t)(g + 3) * W + j];
-        s = ((s + v0) + v1) + v2 + v3;
+    if (j < W) {
+        int g = slice;
+        for (; g + 48 < G; g += 64) {
+            const float v0 = part[(int64_t)g * W + j], v1 = part[(int64_t)(g + 16) * W + j];
+            const float v2 = part[(int64_t)(g + 32) * W + j], v3 = part[(int64_t)(g + 48) * W + j];
+            s = (((s + v0) + v1) + v2) + v3;
+        }
+        for (; g < G; g += 16) s += part[(int64_t)g * W + j];
     }
-    for (; g < G; ++g) s += part[(int64_t)g * W + j];
-    out[j] = s;
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (slice == 0 && j < W) {
+        float t = red[threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += red[threadIdx.x + 16 * q];
+        out[j] = t;
+    }
 }
 
 size_t attn_image_floats(int L, int D) { return (size_t)((L + 31) / 32) * D * 96; }      // 6 bytes per (padded) weight x 2 projections
@@ -663,7 +721,7 @@ size_t attn_ws_floats(int64_t N, int L, int D, int K) {
 
 size_t attn_bwd_ws_floats(int64_t N, int L, int D, int K) {
     const int64_t G = (N + AT_ROWS - 1) / AT_ROWS;
-    return attn_image_floats(L, D) + (size_t)G * (2 + K) * D + (size_t)K * N;
+    return attn_image_floats(L, D) + (size_t)G * (2 + K) * D + (size_t)K * N + (size_t)G * K * 4 + 4;
 }
 
 template <bool BWD>
@@ -731,12 +789,14 @@ extern "C" size_t moc_gated_attention_backward_workspace(int64_t N, int L, int D
     return attn_bwd_ws_floats(N, L, D, K) * sizeof(float);
 }
 
+extern "C" int moc_gated_attention_dab_stride(int D, int K) { return attn_dab_stride(D, K); }
+
 extern "C" int moc_gated_attention_backward(const float* h, int64_t N, int L, const float* Wa, const float* ba,
                                             const float* Wb, const float* bb, int D, const float* Wc, int K,
-                                            const float* A_raw, const float* gA, const float* gM, float* dab, float* p,
-                                            float* ds, float* dcol, void* workspace, size_t workspace_bytes,
+                                            const float* A_raw, const float* gA, const float* gM, float* dab,
+                                            float* ds, float* dcol, float* dbc, void* workspace, size_t workspace_bytes,
                                             moc_stream_t stream) {
-    MOC_REQUIRE(h && Wa && ba && Wb && bb && Wc && A_raw && dab && p && ds && dcol && workspace,
+    MOC_REQUIRE(h && Wa && ba && Wb && bb && Wc && A_raw && dab && ds && dcol && dbc && workspace,
                 "moc_gated_attention_backward: null pointer");
     MOC_REQUIRE(N >= 1 && N < (1ll << 31), "moc_gated_attention_backward: bad N=%lld", (long long)N);
     MOC_REQUIRE(L >= 16 && L % 16 == 0 && L <= 4096, "moc_gated_attention_backward: L=%d must be a multiple of 16 (<= 4096)", L);
@@ -752,14 +812,13 @@ extern "C" int moc_gated_attention_backward(const float* h, int64_t N, int L, co
     float* img = (float*)workspace;
     float* colpart = img + attn_image_floats(L, D);
     float* dp = colpart + (size_t)G * (2 + K) * D;
+    float4* part = (float4*)(((uintptr_t)(dp + (size_t)K * N) + 15) & ~(uintptr_t)15);
     const int64_t nfrag = (int64_t)((L + 31) / 32) * 4 * (D / 64) * 2 * 64;
     attn_image_kernel<<<moc_cdiv(nfrag, 256), 256, 0, s>>>(Wa, Wb, L, D, (uint4*)img);
     MOC_CHECK_LAUNCH("moc_gated_attention_backward(image)");
-    if (gM) {
-        attn_bwd_dp_kernel<<<(int)(G < 1024 ? G : 1024), 256, 0, s>>>(h, gM, N, L, K, dp);
-        MOC_CHECK_LAUNCH("moc_gated_attention_backward(dp)");
-    }
-    attn_bwd_ds_kernel<<<K, 1024, 0, s>>>(A_raw, gM ? dp : nullptr, gA, N, p, ds);
+    attn_bwd_rows_kernel<<<G, 256, 0, s>>>(h, gM, A_raw, gA, N, L, K, dp, part);
+    MOC_CHECK_LAUNCH("moc_gated_attention_backward(rows)");
+    attn_bwd_ds_kernel<<<dim3((unsigned)moc_cdiv(N, 256), K), 256, 0, s>>>(A_raw, gM ? dp : nullptr, gA, part, N, G, D, K, dab, ds, dbc);
     MOC_CHECK_LAUNCH("moc_gated_attention_backward(ds)");
     AttnBwdArgs a{};
     a.h = h; a.img = (const unsigned char*)img; a.ba = ba; a.bb = bb; a.Wc = Wc;
@@ -767,7 +826,7 @@ extern "C" int moc_gated_attention_backward(const float* h, int64_t N, int L, co
     a.N = N; a.L = L; a.D = D; a.K = K;
     { const int rc = attn_launch<true>(a, G, s, "moc_gated_attention_backward"); if (rc != MOC_OK) return rc; }
     const int W = (2 + K) * D;
-    attn_bwd_colsum_kernel<<<moc_cdiv(W, 256), 256, 0, s>>>(colpart, G, W, dcol);
+    attn_bwd_colsum_kernel<<<moc_cdiv(W, 16), 256, 0, s>>>(colpart, G, W, dcol);
     MOC_CHECK_LAUNCH("moc_gated_attention_backward(colsum)");
     return MOC_OK;
 }

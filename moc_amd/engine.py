@@ -532,7 +532,7 @@ def gated_attention_pool(h: torch.Tensor, Wa, ba, Wb, bb, Wc, bc):
 
 def gated_attention_backward(h, Wa, ba, Wb, bb, Wc, A_raw, gA=None, gM=None):
     """The backward of gated_attention_pool (include/moc_hip.h moc_gated_attention_backward; autograd's work behind
-    models/model_clam.py:58-63, :178-183, :206).  One recompute pass in HIP, then the three plain GEMMs as library calls.
+    models/model_clam.py:58-63, :178-183, :206).  One recompute pass in HIP, then two plain GEMMs as library calls.
     -> (dh [N, L], dWa [D, L], dba [D], dWb [D, L], dbb [D], dWc [K, D], dbc [K])."""
     ts = [h, Wa, ba, Wb, bb, Wc, A_raw] + [g for g in (gA, gM) if g is not None]
     assert all(t.is_cuda and t.dtype == torch.float32 for t in ts), "gated_attention_backward: fp32 tensors on the GPU"
@@ -544,18 +544,21 @@ def gated_attention_backward(h, Wa, ba, Wb, bb, Wc, A_raw, gA=None, gM=None):
     assert Wa.shape == Wb.shape == (D, L) and Wc.shape == (K, D) and A_raw.shape == (K, N)
     assert (gA is None or gA.shape == (K, N)) and (gM is None or gM.shape == (K, L))
     dev = h.device
-    dab = torch.empty((N, 2 * D), dtype=torch.float32, device=dev)
-    p = torch.empty((K, N), dtype=torch.float32, device=dev)
+    S = lib().moc_gated_attention_dab_stride(D, K)
+    dab = torch.empty((N, S), dtype=torch.float32, device=dev)     # da | db | p | 0
     ds = torch.empty((K, N), dtype=torch.float32, device=dev)
     dcol = torch.empty(((2 + K) * D,), dtype=torch.float32, device=dev)
+    dbc = torch.empty((K,), dtype=torch.float32, device=dev)
     nbytes = lib().moc_gated_attention_backward_workspace(N, L, D, K)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     check(lib().moc_gated_attention_backward(ptr(h), N, L, ptr(Wa), ptr(ba), ptr(Wb), ptr(bb), D, ptr(Wc), K, ptr(A_raw),
                                              ptr(gA) if gA is not None else None, ptr(gM) if gM is not None else None,
-                                             ptr(dab), ptr(p), ptr(ds), ptr(dcol), ptr(ws), nbytes, _stream()),
+                                             ptr(dab), ptr(ds), ptr(dcol), ptr(dbc), ptr(ws), nbytes, _stream()),
           "moc_gated_attention_backward")
-    dWab = dab.t() @ h                                             # [2 D, L]: dWa over dWb
-    dh = dab @ torch.cat([Wa, Wb], 0)
+    X = torch.zeros((S, L), dtype=torch.float32, device=dev)       # [Wa; Wb; gM; 0]: M = p h rides in the same GEMM
+    X[:D], X[D:2 * D] = Wa, Wb
     if gM is not None:
-        dh.addmm_(p.t(), gM)                                       # M = p h, directly
-    return dh, dWab[:D], dcol[:D], dWab[D:], dcol[D:2 * D], dcol[2 * D:].view(K, D), ds.sum(1)
+        X[2 * D:2 * D + K] = gM
+    dh = dab @ X
+    dW = dab.t() @ h                                               # [S, L]: dWa over dWb (over M)
+    return dh, dW[:D], dcol[:D], dW[D:2 * D], dcol[D:2 * D], dcol[2 * D:].view(K, D), dbc

@@ -8,8 +8,8 @@ the bag on the HIP path (moc_gated_attention_pool: fp32 MFMA projections, gate a
 online softmax; engine.gated_attention_pool); the layers around it (the first fc, the bag and instance
 classifiers) are plain torch GEMMs.  The backward pass is HIP as well (moc_gated_attention_backward): the forward keeps
 neither the [N, D] activations nor the softmax, so one recompute pass (the forward's main loop) turns the arriving
-gradients into those at the two pre-activations, with the gate's derivative taken in registers, and only three plain
-GEMMs (dW = dab^T h, dh = dab [Wa; Wb]) go to the library.
+gradients into those at the two pre-activations, with the gate's derivative taken in registers, and only two plain
+GEMMs (dW = dab^T h, dh = dab [Wa; Wb; gM]) go to the library.
 
 The un-gated network (`gate=False`, Attn_Net: A = Wc tanh(Wa h + ba) + bc) runs through the same kernel with a gate
 that is exactly one: Wb = 0 and bb = 40 give sigmoid(40) = 1 - 4e-18, which IS 1.0f in fp32 (and 1 + e^-40 == 1.0f in
@@ -39,7 +39,7 @@ def initialize_weights(module):
 
 class _GatedAttentionPool(torch.autograd.Function):
     """Forward and backward both in HIP: the backward recomputes the gate in one pass over the bag (nothing but A_raw
-    was kept) and leaves three plain GEMMs to the library (engine.gated_attention_backward)."""
+    was kept) and leaves two plain GEMMs to the library (engine.gated_attention_backward)."""
 
     @staticmethod
     def forward(ctx, h, Wa, ba, Wb, bb, Wc, bc):

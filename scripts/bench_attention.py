@@ -79,7 +79,7 @@ def main():
     print(f"  moc_gated_attention_pool : {us:8.1f} us  {flops / us / 1e6:6.1f} TFLOP/s fp32-exact = {6 * flops / us / 1e6:6.1f} TFLOP/s of bf16 products "
           f"({6 * flops / us / 1e6 / (BF16_MFMA_PEAK / 1e12):.2f} of the bf16 matrix peak; {flops / us / 1e6 / (F32_MFMA_PEAK / 1e12):.2f} x the fp32 matrix peak)")
     print(f"  torch on the same GPU    : {us_t:8.1f} us  (5 library kernels, [N, D] activations through HBM)")
-    print(f"  forward + backward       : {us_fb:8.1f} us  (moc_gated_attention_backward alone, with its three library GEMMs: {us_b:.1f} us); "
+    print(f"  forward + backward       : {us_fb:8.1f} us  (moc_gated_attention_backward alone, with its two library GEMMs: {us_b:.1f} us); "
           f"torch autograd on the same GPU {us_fb_t:.1f} us")
     print(f"  torch on the host cores  : {cpu_us:8.1f} us  ({torch.get_num_threads()} threads)")
 
