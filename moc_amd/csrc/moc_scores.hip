@@ -17,6 +17,7 @@
 // column-major ([stat][slot]) for the column-wise selectors that follow.
 #include <stdlib.h>
 #include "moc_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -152,57 +153,96 @@ __device__ __forceinline__ void row_epilogue(const ScoresArgs& a, const float* t
     (void)ldt;
 }
 
-// all 64 lanes: lane = (part, row) with part = lane >> 4 owning columns part, part + 4, ...; the row's
-// values are read from the wave's tile in one batch of independent LDS reads, the four partial results of
-// a row meet through two xor-shuffles (commutative pairings: every lane of a row gets the same bits)
+// The two partners of a lane under xor 16 / xor 32 without LDS (ds_bpermute) or its lgkmcnt: the gfx950 row swaps.
+// permlane16_swap(x, x) leaves (x[row 0], x[row 1]) in BOTH rows 0 and 1 of the pair (rows 2, 3 alike), permlane32_swap
+// the two halves: every lane of a pair then holds the same (lo, hi), so a commutative merge gives both the same bits.
+template <int OFF>
+__device__ __forceinline__ void xor_pair(float x, float& lo, float& hi) {
+    static_assert(OFF == 16 || OFF == 32, "row swaps");
+    const unsigned xi = __float_as_uint(x);
+    if constexpr (OFF == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+        lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+        lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+    }
+}
+
 // The statistics of one row from its Q*4 column values spread over the row's four lanes (lane = (part, row), part owning
-// columns part, part + 4, ...): the four partial results meet through two xor-shuffles (commutative pairings: every
-// lane of a row gets the same bits).
+// columns part, part + 4, ...): class columns q < qc, extension columns qc <= q < qe of this lane.  The wave spends more
+// cycles here than in its MFMAs when it is alone on its SIMD (three n-tiles: 4,400 of 9,800 cycles per tile before this
+// form, scripts/diag_score_phases.py), so the form is branch-free and short: masked values instead of predicated code,
+// top-2 by min / max, the cross-lane merges by row swaps, exp as v_exp_f32 of (v - max) log2(e) -- exactly 1 at the
+// maximum, relative error 2e-7 elsewhere, no denormal tail -- and ONE division per row (p = e * (1 / den)).
 template <int Q>
 __device__ __forceinline__ void row_stats_emit(const ScoresArgs& a, const float (&v)[Q], int64_t slot_base, int row0, int nk) {
     const int lane = threadIdx.x & 63, row = lane & 15, part = lane >> 4;
     const int C = a.C, Ce = a.Ce;
+    const int qc = (C - part + 3) >> 2, qe = (Ce - part + 3) >> 2;          // c = 4 q + part < C  <=>  q < qc
+    float vm[Q];
     float m1 = -INFINITY, m2 = -INFINITY, bsum = 0.f, bmax = -INFINITY;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const int c = q * 4 + part;
-        if (c < C) {
-            if (v[q] > m1) { m2 = m1; m1 = v[q]; } else if (v[q] > m2) { m2 = v[q]; }
-        } else if (c < Ce) {
-            bsum += v[q];
-            bmax = fmaxf(bmax, v[q]);
-        }
+        const bool cls = q < qc, ext = q >= qc && q < qe;
+        vm[q] = cls ? v[q] : -INFINITY;
+        m2 = fmaxf(m2, fminf(m1, vm[q]));                  // duplicates of the maximum count (gap 0), as topk(2)
+        m1 = fmaxf(m1, vm[q]);
+        bsum += ext ? v[q] : 0.f;
+        bmax = fmaxf(bmax, ext ? v[q] : -INFINITY);
     }
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-        const float o1 = __shfl_xor(m1, off, 64), o2 = __shfl_xor(m2, off, 64);
-        m2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));          // duplicates of the maximum count (gap 0), as topk(2)
-        m1 = fmaxf(m1, o1);
-        bsum += __shfl_xor(bsum, off, 64);
-        bmax = fmaxf(bmax, __shfl_xor(bmax, off, 64));
-    }
+    auto merge = [&](auto off) {
+        constexpr int OFF = decltype(off)::value;
+        float a1, b1, a2, b2, s0, s1, x0, x1;
+        xor_pair<OFF>(m1, a1, b1); xor_pair<OFF>(m2, a2, b2); xor_pair<OFF>(bsum, s0, s1); xor_pair<OFF>(bmax, x0, x1);
+        m2 = fmaxf(fminf(a1, b1), fmaxf(a2, b2));
+        m1 = fmaxf(a1, b1);
+        bsum = s0 + s1;
+        bmax = fmaxf(x0, x1);
+    };
+    merge(std::integral_constant<int, 16>{});
+    merge(std::integral_constant<int, 32>{});
     float e[Q], den = 0.f;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        e[q] = (q * 4 + part < C) ? expf(v[q] - m1) : 0.f;
+        e[q] = __builtin_amdgcn_exp2f((vm[q] - m1) * 1.44269504088896340736f);       // exp2(-inf) = 0: the masked columns
         den += e[q];
     }
-    den += __shfl_xor(den, 16, 64);
-    den += __shfl_xor(den, 32, 64);
+    {
+        float d0, d1;
+        xor_pair<16>(den, d0, d1); den = d0 + d1;
+        xor_pair<32>(den, d0, d1); den = d0 + d1;
+    }
     if (row0 + row >= nk) return;
-    float* s = a.stats + slot_base + row0 + row;
+#ifdef MOC_STAMPS
+    if (a.tpw == 7) {                                  // diagnostic (MOC_EPI_MODE=7): everything computed, nothing stored
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const float pq = e[q] / den; asm volatile("" ::"v"(pq), "v"(v[q])); }
+        asm volatile("" ::"v"(m1), "v"(m2), "v"(bsum), "v"(bmax));
+        return;
+    }
+#endif
+    const float rden = 1.f / den;
+    // column c of the statistics starts at stats + c * stride: a uniform base per q, one 32-bit lane offset for all
+    const int64_t stride = a.stride;
+    float* sv = a.stats + slot_base;
+    float* sp = sv + (int64_t)C * stride;
+    const unsigned off = (unsigned)((int64_t)part * stride + (row0 + row));
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const int c = q * 4 + part;
-        if (c < C) {
-            s[(int64_t)c * a.stride] = v[q];
-            s[(int64_t)(C + c) * a.stride] = e[q] / den;
+        if (q < qc) {
+            sv[off] = v[q];
+            sp[off] = e[q] * rden;
         }
+        sv += 4 * stride;
+        sp += 4 * stride;
     }
-    if (part == 0) s[(int64_t)(2 * C) * a.stride] = fabsf(m1 - m2);
-    else if (part == 1) s[(int64_t)(2 * C + 1) * a.stride] = bsum;
-    else if (part == 2) s[(int64_t)(2 * C + 2) * a.stride] = bmax;
-    else a.sel_flag[slot_base + row0 + row] = 0;
+    if (part < 3) {
+        const float t = part == 0 ? fabsf(m1 - m2) : part == 1 ? bsum : bmax;
+        a.stats[slot_base + (int64_t)(2 * C + part) * stride + row0 + row] = t;
+    } else {
+        a.sel_flag[slot_base + row0 + row] = 0;
+    }
 }
 
 // all 64 lanes: the row's values are read from the wave's 16 x (NT*16) tile in one batch of independent LDS reads
@@ -387,6 +427,21 @@ __device__ __forceinline__ void compute_pairs_impl(const u32x4_t (&buf)[NF], u32
 // bank image (NT x img) resident in LDS: NT > 1 leaves room for one workgroup per CU only.
 // The launch covers slides [slide0, slide0 + n_slides) (the launcher chunks a batch whose per-slide
 // metadata would not fit beside the image).
+// diagnostic build (-DMOC_STAMPS): shader cycles wave 0 of workgroup 0 spends in each phase of the walk -- 0: locate,
+// 4: issue of the next unit's loads, 1: wait for this unit's loads, 2: LDS reads + MFMAs, 3: row epilogue -- summed over
+// its units into g_moc_stamps[40 + phase], units in [46].  Every stamp sits where no counted LDS read is outstanding
+// (s_memtime returns through lgkmcnt).  scripts/diag_score_phases.py reads them.
+#ifdef MOC_STAMPS
+#define MOC_PHASE_DECL() unsigned long long ph_t = 0, ph_acc[5] = {0, 0, 0, 0, 0}, ph_n = 0
+#define MOC_PHASE_BEGIN() ph_t = __builtin_amdgcn_s_memtime()
+#define MOC_PHASE(id) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[id] += t_ - ph_t; ph_t = t_; if ((id) == 1) ++ph_n; } while (0)
+#define MOC_PHASE_END() do { if (threadIdx.x == 0 && blockIdx.x == 0) { for (int q_ = 0; q_ < 5; ++q_) g_moc_stamps[40 + q_] = ph_acc[q_]; g_moc_stamps[46] = ph_n; g_moc_stamps[47] = NT; } } while (0)
+#else
+#define MOC_PHASE_DECL() do { } while (0)
+#define MOC_PHASE_BEGIN() do { } while (0)
+#define MOC_PHASE(id) do { } while (0)
+#define MOC_PHASE_END() do { } while (0)
+#endif
 template <int NF, bool BF16, int NT, bool F16 = false>
 __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(ScoresArgs a, int slide0, int n_slides) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -477,6 +532,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
         u.kk0 = ch * NF;
         u.last = ch == U - 1;
     };
+    MOC_PHASE_DECL();
     f32x4_t acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -508,6 +564,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
         };
         asm_lds_batch<0, PER, NT, 0, NB>(B0, bbase);
         compute_pairs_impl<0, NF, PER, NT, NB>(buf, B0, B1, bbase, mac);
+        MOC_PHASE(2);
         if (u.last) {
             wave_lds_order();
 #pragma unroll
@@ -518,6 +575,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
             row_epilogue_wide<NT>(a, tile, u.base, u.row0, u.nk);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            MOC_PHASE(3);
         }
     };
     // Flattened (tile, unit) walk, two register buffers.  The tile loads are inline asm so that the
@@ -530,19 +588,23 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
     u32x4_t bufA[NF], bufB[NF];
     Unit uA, uB;
     if (g < total) { locate(g, ch, uA); asm_issue<0, NF>(bufA, uA.p); }
+    MOC_PHASE_BEGIN();
     while (g < total) {
         advance();
         const bool moreB = g < total;
-        if (moreB) { locate(g, ch, uB); asm_issue<0, NF>(bufB, uB.p); asm_wait_keep<NF, NF>(bufA); }
+        if (moreB) { locate(g, ch, uB); MOC_PHASE(0); asm_issue<0, NF>(bufB, uB.p); MOC_PHASE(4); asm_wait_keep<NF, NF>(bufA); }
         else asm_wait_keep<0, NF>(bufA);
+        MOC_PHASE(1);
         compute(bufA, uA);
         if (!moreB) break;
         advance();
         const bool moreA = g < total;
-        if (moreA) { locate(g, ch, uA); asm_issue<0, NF>(bufA, uA.p); asm_wait_keep<NF, NF>(bufB); }
+        if (moreA) { locate(g, ch, uA); MOC_PHASE(0); asm_issue<0, NF>(bufA, uA.p); MOC_PHASE(4); asm_wait_keep<NF, NF>(bufB); }
         else asm_wait_keep<0, NF>(bufB);
+        MOC_PHASE(1);
         compute(bufB, uB);
     }
+    MOC_PHASE_END();
 }
 
 // ---- wide banks (16-bit storage, 4..8 n-tiles): K-split form --------------------------------------
@@ -937,6 +999,9 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
     // parks in-flight load destinations in AGPRs -- tests/test_isa_hazards_cpu.py)
     if (a.NT <= (bf ? 3 : 4) && fixed + 24 <= 160 * 1024) {
         a.tpw = 0;
+#ifdef MOC_STAMPS
+        if (const char* em = getenv("MOC_EPI_MODE")) a.tpw = atoi(em);     // diagnostic: row_stats_emit
+#endif
         const int chunk_max = (int)((160 * 1024 - fixed) / 24);
         const int chunk = B->n_slides < chunk_max ? B->n_slides : chunk_max;
         const size_t smem = fixed + (size_t)chunk * 24;
