@@ -504,10 +504,30 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
     // the array was written by the previous kernel and is read-only here).
     typedef const int32_t __attribute__((address_space(4))) * kept_sptr;
     kept_sptr kept_s = (kept_sptr)(uintptr_t)a.kept;
+    // The slide of a tile.  A wave's next tile lies `stride` tiles on -- rarely more than a few slides away -- so the
+    // search starts at the slide of the previous tile and reads the next three boundaries at once (one LDS round trip
+    // for up to three steps); only the first tile of a wave takes the binary search.  (One binary search per tile --
+    // seven dependent LDS reads with nothing to hide them behind when the wave is alone on its SIMD -- was 1,700 of a
+    // tile's 7,400 cycles at three n-tiles: scripts/diag_score_phases.py.)
+    int cb = -1;                                                // slide of the previous tile (scalar)
     auto locate = [&](int g, int ch, Unit& u) {
-        int lo = 0, hi = n_slides;                 // prefix[lo] <= g < prefix[hi]
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= g) lo = mid; else hi = mid; }
-        const int b = __builtin_amdgcn_readfirstlane(lo);
+        int b;
+        if (cb < 0) {
+            int lo = 0, hi = n_slides;                         // prefix[lo] <= g < prefix[hi]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= g) lo = mid; else hi = mid; }
+            b = __builtin_amdgcn_readfirstlane(lo);
+        } else {
+            b = cb;
+            for (;;) {                                         // (uniform: every lane reads the same words)
+                const int i1 = b + 1 < n_slides ? b + 1 : n_slides, i2 = b + 2 < n_slides ? b + 2 : n_slides;
+                const int i3 = b + 3 < n_slides ? b + 3 : n_slides;
+                const int p1 = prefix[i1], p2 = prefix[i2], p3 = prefix[i3];
+                const int adv = (g >= p1) + (g >= p2) + (g >= p3);                   // prefix is non-decreasing; g < prefix[n_slides]
+                b = __builtin_amdgcn_readfirstlane(b + adv);
+                if (adv < 3) break;
+            }
+        }
+        cb = b;
         u.base = s_base[b];
         const int64_t xbase = s_xbase[b];
         u.nk = __builtin_amdgcn_readfirstlane(s_nk[b]);
