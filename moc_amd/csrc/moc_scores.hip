@@ -213,7 +213,7 @@ __device__ __forceinline__ void row_stats_emit(const ScoresArgs& a, const float 
         xor_pair<16>(den, d0, d1); den = d0 + d1;
         xor_pair<32>(den, d0, d1); den = d0 + d1;
     }
-    if (row0 + row >= nk) return;
+    if ((unsigned)(row0 + row) >= (unsigned)nk) return;          // beyond the slide (or, in a short first tile, before it)
 #ifdef MOC_STAMPS
     if (a.tpw == 7) {                                  // diagnostic (MOC_EPI_MODE=7): everything computed, nothing stored
 #pragma unroll
@@ -483,7 +483,10 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
         for (int c0 = 0; c0 < n_slides; c0 += 64) {
             const int b = c0 + lane;
             int v = 0;
-            if (b < n_slides) v = (s_nk[b] + 15) >> 4;
+            // tiles are cut at ABSOLUTE multiples of 16 slots (the first tile of a slide is short when its base is not
+            // one): every 64-byte piece of statistics a tile writes is then 64-byte aligned -- 7 % of the launch at
+            // three n-tiles, 2.5 % at one, against bases at odd multiples of 8
+            if (b < n_slides && s_nk[b] > 0) v = (s_nk[b] + (int)(s_base[b] & 15) + 15) >> 4;
             int inc = v;
             for (int off = 1; off < 64; off <<= 1) {
                 const int o = __shfl_up(inc, off, 64);
@@ -531,10 +534,11 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
         u.base = s_base[b];
         const int64_t xbase = s_xbase[b];
         u.nk = __builtin_amdgcn_readfirstlane(s_nk[b]);
-        u.row0 = __builtin_amdgcn_readfirstlane((g - prefix[b]) * 16);
+        u.row0 = __builtin_amdgcn_readfirstlane((g - prefix[b]) * 16 - (int)(u.base & 15));     // < 0 in a short first tile
         int sel = lane & 15;
-        const int last_valid = u.nk - 1 - u.row0;                  // >= 0: the tile exists
-        sel = sel < last_valid ? sel : last_valid;                 // clamp: loads stay in bounds
+        const int first_valid = u.row0 < 0 ? -u.row0 : 0, last_valid = u.nk - 1 - u.row0;          // the tile holds a row
+        sel = sel > first_valid ? sel : first_valid;               // clamp: loads stay in the slide
+        sel = sel < last_valid ? sel : last_valid;
         int r = u.row0 + sel;
         if (a.kept) {
             const int idx = __builtin_amdgcn_readfirstlane((int)u.base + u.row0);
@@ -1028,7 +1032,7 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
         MOC_REQUIRE(a.NT > 1 || chunk == B->n_slides, "moc_scores: D=%d / n_slides=%d need %zu B of LDS (> 160 KiB)",
                     B->D, B->n_slides, fixed + (size_t)B->n_slides * 24);
         int64_t tiles = 0;   // upper bound from the host-known sizes
-        tiles = (B->total_rows + 15) / 16 + B->n_slides;
+        tiles = (B->total_rows + 15) / 16 + 2 * (int64_t)B->n_slides;
         int wgs = (int)((tiles + 3) / 4);
         const int resident = 256 * (smem <= 80 * 1024 ? 2 : 1);
         if (wgs > resident) wgs = resident;
