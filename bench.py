@@ -404,7 +404,9 @@ def main():
     value, dt, loop, exchange = r["value"], r["dt"], r["loop"], r["exchange"]
     res, model = r["res"], r["model"]
 
-    # ---- roofline of the dominant kernel (score pass), from live events on the launch stream
+    # ---- roofline of the dominant kernel (score pass), from live HIP events on the launch stream that carry the
+    # kernel's own start / end stamps (moc_scores_timed: hipExtLaunchKernel), so that the duration is the one rocprofv3
+    # reports for the same launch -- an event pair recorded AROUND the launch adds the queue's 10-15 us on a busy GPU
     ev = r["events"]
     ms = [s.elapsed_time(e) for s, e, _ in ev]
     by = [b for _, _, b in ev]
@@ -446,11 +448,7 @@ def main():
         torch.cuda.synchronize()
         iso = []
         for _ in range(10):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            check = engine.check
-            e0.record()
-            check(engine.lib().moc_scores(engine.C.byref(last.c), engine.ptr(M._bank_for(Xl, dev).image), engine._stream()), "moc_scores")
-            e1.record()
+            e0, e1 = engine.timed_scores(last, M._bank_for(Xl, dev))
             torch.cuda.synchronize()
             iso.append(e0.elapsed_time(e1))
         iso_ms = sorted(iso)[len(iso) // 2]

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 12
+#define MOC_ABI_VERSION 13
 
 enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
 
@@ -167,6 +167,10 @@ int64_t moc_host_max_kept(const uint8_t* mask, const int64_t* row_off_host, int 
  * (main_moc.py:336-337, :360-365; patch_selection_classifier_index.py:34, :46-48, :75).
  * Also clears sel_flag. */
 int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t stream);
+/* moc_scores with two hipEvent_t (created with timing enabled) that receive the score kernel's own start and end
+ * time stamps (hipExtLaunchKernel): hipEventElapsedTime(start, stop) is then the kernel's duration as a profiler
+ * reports it, whatever else the GPU is running.  bench.py's `roofline` uses it. */
+int moc_scores_timed(const moc_batch_t* B, const void* bank, moc_stream_t stream, void* start_event, void* stop_event);
 
 /* The same statistics from an already computed logits matrix (device [N, Ct] row-major,
  * first C columns foreground): stats_out is [2C+3, N].  For callers that hold logits, not

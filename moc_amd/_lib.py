@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 MOC_F32, MOC_BF16, MOC_F16 = 0, 1, 2
 SEL_BITS = {"topk": 1, "delta_softmax": 2, "delta_diff": 4, "bottomk": 8}
@@ -60,6 +60,7 @@ SIGNATURES = {
     "moc_host_max_kept": (C.c_int64, [_p, _p, C.c_int]),
     "moc_mask_compact": (C.c_int, [_BP, _p]),
     "moc_scores": (C.c_int, [_BP, _p, _p]),
+    "moc_scores_timed": (C.c_int, [_BP, _p, _p, _p, _p]),
     "moc_row_stats": (C.c_int, [_p, C.c_int64, C.c_int, C.c_int, _p, _p]),
     "moc_select": (C.c_int, [_BP, _p]),
     "moc_gather_candidates": (C.c_int, [_BP, _p, _p]),

@@ -17,6 +17,7 @@
 // column-major ([stat][slot]) for the column-wise selectors that follow.
 #include <stdlib.h>
 #include "moc_common.h"
+#include <hip/hip_ext.h>
 #include <type_traits>
 
 namespace {
@@ -997,7 +998,10 @@ extern "C" int moc_mask_compact(const moc_batch_t* B, moc_stream_t stream) {
     return MOC_OK;
 }
 
-extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t stream) {
+// ev0 / ev1 (nullable): HIP events that take the score kernel's OWN start and end time stamps (hipExtLaunchKernel: the
+// dispatch's profiling stamps, not the moment a marker packet reaches the queue -- an event pair recorded around the
+// launch on a busy GPU measured 59 us for a kernel rocprofv3 times at 47).  A batch launched in chunks: first / last.
+static int scores_impl(const moc_batch_t* B, const void* bank, moc_stream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (int rc = moc_check_batch(B, "moc_scores")) return rc;
     MOC_REQUIRE(bank && B->stats && B->sel_flag, "moc_scores: null bank/stats/sel_flag");
     ScoresArgs a;
@@ -1044,7 +1048,8 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
                 (void)hipFuncSetAttribute((const void*)scores_stream_kernel<NF, BF, NTT, FH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                 attr_set = true;                                                                        \
             }                                                                                           \
-            scores_stream_kernel<NF, BF, NTT, FH><<<wgs, 256, smem, s>>>(a, s0, ns);                    \
+            hipExtLaunchKernelGGL((scores_stream_kernel<NF, BF, NTT, FH>), dim3(wgs), dim3(256), smem, s,  \
+                                  (s0 == 0 ? ev0 : nullptr), (s0 + ns == B->n_slides ? ev1 : nullptr), 0, a, s0, ns); \
         } while (0)
 #define MOC_LAUNCH_STREAM_NT(NF, BF, FH)                                                                \
         do {                                                                                            \
@@ -1086,8 +1091,8 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
                 else (void)hipFuncSetAttribute((const void*)scores_wide_kernel<NTT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                 attr_set[f16] = true;                                                                   \
             }                                                                                           \
-            if (f16) scores_wide_kernel<NTT, true><<<grid_w, 256, smem_w, s>>>(a);                      \
-            else scores_wide_kernel<NTT, false><<<grid_w, 256, smem_w, s>>>(a);                         \
+            if (f16) hipExtLaunchKernelGGL((scores_wide_kernel<NTT, true>), grid_w, dim3(256), smem_w, s, ev0, ev1, 0, a); \
+            else hipExtLaunchKernelGGL((scores_wide_kernel<NTT, false>), grid_w, dim3(256), smem_w, s, ev0, ev1, 0, a);    \
         } while (0)
         if (a.NT <= 5) {                                               // (6 n-tiles: the register ring spills)
             const size_t ring = (size_t)3 * ((size_t)((a.NT * 3 + 3) / 4) * 4 * 1024);         // three image slots
@@ -1100,8 +1105,8 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
                     else (void)hipFuncSetAttribute((const void*)scores_wide_ring_kernel<NTT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                     attr_set[f16] = true;                                                               \
                 }                                                                                       \
-                if (f16) scores_wide_ring_kernel<NTT, true><<<grid_w, 256, smem_r, s>>>(a);             \
-                else scores_wide_ring_kernel<NTT, false><<<grid_w, 256, smem_r, s>>>(a);                \
+                if (f16) hipExtLaunchKernelGGL((scores_wide_ring_kernel<NTT, true>), grid_w, dim3(256), smem_r, s, ev0, ev1, 0, a); \
+                else hipExtLaunchKernelGGL((scores_wide_ring_kernel<NTT, false>), grid_w, dim3(256), smem_r, s, ev0, ev1, 0, a);    \
             } while (0)
             if (a.NT == 4) MOC_LAUNCH_RING(4);
             else MOC_LAUNCH_RING(5);
@@ -1133,7 +1138,7 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
             (void)hipFuncSetAttribute((const void*)scores_kernel<CH, BF, FH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                            \
         }                                                                                               \
-        scores_kernel<CH, BF, FH><<<grid, block, smem, s>>>(a);                                         \
+        hipExtLaunchKernelGGL((scores_kernel<CH, BF, FH>), grid, block, smem, s, ev0, ev1, 0, a);       \
     } while (0)
     if (B->D % 512 == 0) {
         if (f16) MOC_LAUNCH_SCORES(512, true, true);
@@ -1147,6 +1152,15 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
 #undef MOC_LAUNCH_SCORES
     MOC_CHECK_LAUNCH("moc_scores");
     return MOC_OK;
+}
+
+extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t stream) {
+    return scores_impl(B, bank, stream, nullptr, nullptr);
+}
+
+extern "C" int moc_scores_timed(const moc_batch_t* B, const void* bank, moc_stream_t stream, void* start_event, void* stop_event) {
+    MOC_REQUIRE(start_event && stop_event, "moc_scores_timed: null event");
+    return scores_impl(B, bank, stream, (hipEvent_t)start_event, (hipEvent_t)stop_event);
 }
 
 extern "C" int moc_row_stats(const float* logits, int64_t N, int Ct, int C, float* stats, moc_stream_t stream) {

@@ -24,6 +24,18 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def timed_scores(batch, bank):
+    """moc_scores_timed on the current stream: -> (start, stop) torch events holding the score kernel's own time stamps
+    (start.elapsed_time(stop) after a synchronisation = the kernel's duration as rocprofv3 reports it)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()                                   # (torch creates the HIP event at its first record)
+    e1.record()
+    h0, h1 = e0.cuda_event, e1.cuda_event
+    assert h0 and h1, "torch did not hand out the HIP event handles"
+    check(lib().moc_scores_timed(C.byref(batch.c), ptr(bank.image), _stream(), C.c_void_p(h0), C.c_void_p(h1)), "moc_scores_timed")
+    return e0, e1
+
+
 def _dtype_code(dt: torch.dtype) -> int:
     if dt == torch.float32:
         return _lib.MOC_F32
@@ -153,10 +165,7 @@ class SlideBatch:
             return
         # same four launches, with events around the score pass
         check(lib().moc_mask_compact(C.byref(self.c), _stream()), "moc_mask_compact")
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib().moc_scores(C.byref(self.c), ptr(bank.image), _stream()), "moc_scores")
-        e1.record()
+        e0, e1 = timed_scores(self, bank)
         SCORE_EVENTS.append((e0, e1, self.kept_rows_host * self.D * self.X.element_size()))
         self.select()
         self.gather_candidates()
