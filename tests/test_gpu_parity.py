@@ -77,6 +77,55 @@ def test_scores_many_slides_wide_bank_is_chunked_consistently(dev, dtype):
     np.testing.assert_allclose(many.stats[:C].t().cpu().numpy(), (xr @ W).numpy(), atol=TIGHT, rtol=0)
 
 
+@pytest.mark.parametrize("C", [2, 30])
+def test_scores_short_first_tiles_and_masked_slots(dev, C):
+    """The streaming kernel cuts tiles at absolute multiples of 16 slots: a slide whose base is not one starts with a
+    short tile (1 ... 15 rows), slides of 1 ... 17 rows may lie inside one tile of their neighbours' numbering.  Row for
+    row the statistics must equal those of one long slide (every row is independent), and with a row mask slot
+    base + j must hold the statistics of the j-th kept row."""
+    E = _engine()
+    D = 512
+    W, We = synth.make_bank(41, D, C)
+    sizes = [1, 7, 8, 9, 15, 16, 17, 31, 33, 3, 1, 64, 100, 2, 14, 1, 1, 47, 16, 5]
+    T = sum(sizes)
+    x = synth.make_bag(42, T, D, We, C, label=1).to(torch.bfloat16).to(dev).contiguous()
+    bank = E.Bank.get(W, We, torch.bfloat16, dev)
+    one = E.SlideBatch(x, [T], C, C + 4, 10, 10)
+    one.scores(bank)
+    many = E.SlideBatch(x, sizes, C, C + 4, 10, 10)
+    many.scores(bank)
+    assert torch.equal(many.stats, one.stats)
+    g = torch.Generator().manual_seed(43)
+    mask = torch.rand(T, generator=g) > 0.5
+    mask[:1] = True                                              # (slides that keep no row are allowed; keep the first one non-empty)
+    masked = E.SlideBatch(x, sizes, C, C + 4, 10, 10, mask=mask)
+    masked.scores(bank)
+    st, ref = masked.stats.cpu(), one.stats.cpu()
+    nk = masked.n_kept.cpu().tolist()
+    base = 0
+    for i, n in enumerate(sizes):
+        kept = torch.nonzero(mask[base:base + n]).flatten()
+        assert nk[i] == len(kept)
+        assert torch.equal(st[:, base:base + len(kept)], ref[:, base + kept]), f"slide at {base} ({n} rows, {len(kept)} kept)"
+        base += n
+
+
+def test_scores_timed_is_the_same_launch_with_the_kernels_own_stamps(dev):
+    """moc_scores_timed (bench.py's roofline): the same statistics as moc_scores, and two events whose distance is a
+    kernel's duration -- microseconds, not the milliseconds of a host round trip."""
+    E = _engine()
+    C, D, N = 2, 512, 20000
+    W, We = synth.make_bank(51, D, C)
+    x = synth.make_bag(52, N, D, We, C, label=0).to(torch.bfloat16).to(dev).contiguous()
+    bank = E.Bank.get(W, We, torch.bfloat16, dev)
+    a, b = E.SlideBatch(x, [N], C, C + 4, 10, 10), E.SlideBatch(x, [N], C, C + 4, 10, 10)
+    a.scores(bank)
+    e0, e1 = E.timed_scores(b, bank)
+    torch.cuda.synchronize()
+    assert torch.equal(a.stats, b.stats)
+    assert 1e-3 < e0.elapsed_time(e1) < 5.0
+
+
 def test_scores_uses_W_for_foreground_and_Wext_for_background(dev):
     """main_moc.py:336-337: logits come from W, only the background from W_ext."""
     E = _engine()
