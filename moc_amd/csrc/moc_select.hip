@@ -346,8 +346,22 @@ __global__ __launch_bounds__(1024) void topk_mean_kernel(TopkArgs a) {
         unsigned long long* cand = reinterpret_cast<unsigned long long*>(((uintptr_t)(hist + 288) + 7) & ~(uintptr_t)7);   // [TK_CAND]
         int* wmax_s = wave_tot;                                         // [16] per-wave maxima, then [16] = T0
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        // up to 16 keys per thread stay in registers between the two sweeps (n <= 16,384: every union of the reference's
+        // configurations); longer segments read the keys again (L2)
+        constexpr int RK = 16;
+        const bool in_regs = n <= RK * 1024;
+        uint32_t kr[RK];
         uint32_t mx = 0;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) { const uint32_t u = keyfn(i); mx = u > mx ? u : mx; }
+        if (in_regs) {
+#pragma unroll
+            for (int q = 0; q < RK; ++q) {
+                const int i = (int)threadIdx.x + q * 1024;
+                kr[q] = i < n ? keyfn(i) : 0u;
+                mx = kr[q] > mx ? kr[q] : mx;
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) { const uint32_t u = keyfn(i); mx = u > mx ? u : mx; }
+        }
         mx = (uint32_t)(wave_max_u64((unsigned long long)mx));
         if (lane == 0) wmax_s[wave] = (int)mx;
         __syncthreads();
@@ -362,17 +376,35 @@ __global__ __launch_bounds__(1024) void topk_mean_kernel(TopkArgs a) {
         }
         __syncthreads();
         const uint32_t T0 = (uint32_t)wmax_s[16];
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint32_t u = keyfn(i);
+        auto offer = [&](uint32_t u, int i) {
             if (u >= T0) {
                 const int pos = atomicAdd(&n_list, 1);
                 if (pos < TK_CAND) cand[pos] = ((unsigned long long)u << 32) | (uint32_t)(~(uint32_t)i);
             }
+        };
+        if (in_regs) {
+#pragma unroll
+            for (int q = 0; q < RK; ++q) {
+                const int i = (int)threadIdx.x + q * 1024;
+                if (i < n) offer(kr[q], i);
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) offer(keyfn(i), i);
         }
         __syncthreads();
         const int nc = n_list;
         __syncthreads();
-        if (nc <= TK_CAND) {                                            // (nc >= k: k waves contributed)
+        if (nc <= 64) {                                                 // the usual case: one candidate per lane
+            if (wave == 0) {
+                unsigned long long mine = lane < nc ? cand[lane] : 0ull;
+                for (int r = 0; r < k; ++r) {
+                    const unsigned long long best = wave_max_u64(mine);   // keys are distinct (row in the low word)
+                    mine = mine == best ? 0ull : mine;
+                    if (lane == 0) list[r] = best;
+                }
+            }
+            done = true;
+        } else if (nc <= TK_CAND) {                                     // (nc >= k: k waves contributed)
             if (wave == 0) {
                 unsigned long long mine[TK_CAND / 64];
 #pragma unroll
@@ -434,8 +466,18 @@ __global__ __launch_bounds__(1024) void topk_mean_kernel(TopkArgs a) {
         for (int i = threadIdx.x; i < a.K; i += blockDim.x)
             a.idx_out[(int64_t)out * a.K + i] = i < k ? (int32_t)(~(uint32_t)(list[i] & 0xFFFFFFFFull)) : -1;
     // mean of the k values: gather in rank order, fixed-shape pairwise tree (deterministic)
-    for (int i = threadIdx.x; i < P; i += blockDim.x)
-        lvals[i] = i < k ? vcol[(int)(~(uint32_t)(list[i] & 0xFFFFFFFFull))] : 0.f;
+    // (keys and values in one array -- pooling the mixed scores: the value is the key read backwards, no second gather;
+    // a canonical zero does not say which zero it was)
+    const bool same = a.keys == a.vals && a.key_stride == a.val_stride;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        float v = 0.f;
+        if (i < k) {
+            const uint32_t u = (uint32_t)(list[i] >> 32) ^ flip;
+            if (same && u != 0x80000000u) v = __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+            else v = vcol[(int)(~(uint32_t)(list[i] & 0xFFFFFFFFull))];
+        }
+        lvals[i] = v;
+    }
     __syncthreads();
     if (k <= 64) {
         if (threadIdx.x == 0) {   // short lists: sequential, largest first (as a [k]-row mean would)
