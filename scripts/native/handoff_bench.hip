@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <ctime>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 constexpr int NP = 96, NC = 16, ROWS = 1600, D = 512, STEPS = 2000;
@@ -134,6 +135,39 @@ int main() {
         unsigned to = 0; CHECK(hipMemcpy(&to, tmo, 4, hipMemcpyDeviceToHost));
         printf("rep %d: two launches %.2f us/step   one launch + arrival counter %.2f us/step   (time-outs: %u)\n", rep,
                msA * 1e3 / STEPS, msB * 1e3 / STEPS, to);
+    }
+    // C  the two launches of a 32-step pass captured ONCE in a hipGraph and replayed (the playbook's answer to a
+    //    launch-bound inner loop): the same 64 dispatches per pass, one host call.  GPU time per step and the host
+    //    time of issuing a pass both ways.
+    {
+        constexpr int PASS = 32;
+        hipGraph_t graph; hipGraphExec_t exec;
+        CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        for (int t = 0; t < PASS; ++t) { forward_like<<<NP, 256, 0, s>>>(b); step_like<<<NC, 1024, 0, s>>>(b); }
+        CHECK(hipStreamEndCapture(s, &graph));
+        CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        for (int w = 0; w < 5; ++w) CHECK(hipGraphLaunch(exec, s));
+        CHECK(hipStreamSynchronize(s));
+        const int passes = STEPS / PASS;
+        for (int rep = 0; rep < 3; ++rep) {
+            float msG = 0, msS = 0;
+            timespec t0, t1;
+            CHECK(hipEventRecord(e0, s));
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            for (int p = 0; p < passes; ++p) CHECK(hipGraphLaunch(exec, s));
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            CHECK(hipEventRecord(e1, s)); CHECK(hipStreamSynchronize(s)); CHECK(hipEventElapsedTime(&msG, e0, e1));
+            const double hostG = ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 1e3 / passes;
+            CHECK(hipEventRecord(e0, s));
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            for (int p = 0; p < passes; ++p)
+                for (int t = 0; t < PASS; ++t) { forward_like<<<NP, 256, 0, s>>>(b); step_like<<<NC, 1024, 0, s>>>(b); }
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            CHECK(hipEventRecord(e1, s)); CHECK(hipStreamSynchronize(s)); CHECK(hipEventElapsedTime(&msS, e0, e1));
+            const double hostS = ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 1e3 / passes;
+            printf("rep %d: hipGraph of a 32-step pass %.2f us/step (host %.1f us per pass)   stream launches %.2f us/step (host %.1f us per pass)\n",
+                   rep, msG * 1e3 / (passes * PASS), hostG, msS * 1e3 / (passes * PASS), hostS);
+        }
     }
     return 0;
 }
