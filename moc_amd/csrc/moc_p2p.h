@@ -33,6 +33,7 @@
 #define P2P_LANE() ((int)threadIdx.x)
 #define P2P_CLOCK() wall_clock64()
 #define P2P_PAUSE() __builtin_amdgcn_s_sleep(2)
+#define P2P_LDS_FLAG_CLEAR(p) (*(p) = 0)
 #include "moc_p2p_proto.h"
 
 // host side (moc_p2p.hip)

@@ -51,7 +51,7 @@ P2P_FN bool p2p_signal_wait(const P2pArgs& x, int channel, int* ok_lds) {
             // the exit every wave reaches: the time-out, or an earlier exchange's time-out
             const bool timed_out = P2P_CLOCK() - t0 > x.timeout_ticks;
             if (timed_out || P2P_LD_U_RELAXED_DEV(x.sticky) != 0u) {
-                *ok_lds = 0;
+                P2P_LDS_FLAG_CLEAR(ok_lds);     // (several pollers may clear it at once: the same value)
                 if (timed_out) {         // (a bail-out on the sticky word keeps the error word of the exchange that timed out:
                     P2P_ST_U_RELAXED_DEV(x.sticky, 1u);             // the peer polled NOW may merely be late itself)
                     P2P_ST_I_RELAXED_SYS(x.error, 1 + q);

@@ -39,6 +39,7 @@ static inline float ld_f(const float* p) { float v; __atomic_load(p, &v, __ATOMI
 #define P2P_LANE() tl_lane
 #define P2P_CLOCK() now_ticks()
 #define P2P_PAUSE() std::this_thread::yield()
+#define P2P_LDS_FLAG_CLEAR(p) __atomic_store_n((p), 0, __ATOMIC_RELAXED)   // same-value stores from several threads
 #include "moc_p2p_proto.h"
 
 static const int64_t N_PAR = 96;                    // elements per rank and step (split over the channels)
