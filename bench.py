@@ -29,6 +29,7 @@ the score pass, timed live with events on the launch stream), cpu_baseline (the 
 this box's host cores, bounded sample), eval slides/sec.
 """
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -339,6 +340,11 @@ def main():
             tmp.run(seq + [loop.per_pass], then=(warm + timed)[0])
 
         prime()
+        # (the cyclic collector may not choose the 0.5-40 ms of a timed region for a full collection: one run in a few
+        # dozen measured 11 ms for 100 steps that take 2.4.  Collected HERE, before the warm-up steps -- a pause between
+        # them and the timed region would let the GPU's clocks fall -- and switched off until the regions are over.)
+        gc.collect()
+        gc.disable()
         loop.run(warm, then=timed[0])
         fence()
         exchange = getattr(mdist.train_dp, "exchange", None) if mode.startswith("dp") else None
@@ -383,6 +389,7 @@ def main():
                              "note": "whole epochs of the same model right after the timed region (same process, same "
                                      "clocks): the rate a run of many epochs sees"}
             assert mode == "replicas" or ranks_agree(model), "data-parallel ranks ended the steady-state block with different parameters"
+        gc.enable()
         return out
 
     if a.replicas_only:
