@@ -339,12 +339,13 @@ def main():
                 seq += [m] * (3 if m == loop.per_pass else 1)
             tmp.run(seq + [loop.per_pass], then=(warm + timed)[0])
 
-        prime()
         # (the cyclic collector may not choose the 0.5-40 ms of a timed region for a full collection: one run in a few
-        # dozen measured 11 ms for 100 steps that take 2.4.  Collected HERE, before the warm-up steps -- a pause between
-        # them and the timed region would let the GPU's clocks fall -- and switched off until the regions are over.)
+        # dozen measured 11 ms for 100 steps that take 2.4.  Collected HERE, before the runtime warm-up -- a pause of
+        # milliseconds any later lets the GPU's clocks fall: five warm-up steps do not bring them back, --steps 20 then
+        # measured 23 k instead of 29 k -- and switched off until the regions are over.)
         gc.collect()
         gc.disable()
+        prime()
         loop.run(warm, then=timed[0])
         fence()
         exchange = getattr(mdist.train_dp, "exchange", None) if mode.startswith("dp") else None
