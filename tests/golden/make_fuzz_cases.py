@@ -5,7 +5,7 @@
     draws are reproducible -- with what the sweep reported);
   * a spread drawn from seed 2026: the first cases that add a not-yet-seen (C, dtype), (D, dtype), j, K or discard
     combination, and every case whose union can exceed 4096 / 8192 rows (the wide step kernels' in-kernel pooling and
-    the topk_mean_kernel -> wide step path), then plain draws of seed 2027 until the list holds 64;
+    the topk_mean_kernel -> wide step path), then plain draws of seed 2027 until the list holds 61 + the special cases;
   * eight wide-bank cases (45-76 classes: the K-split ring kernel, the wide step, the general three-launch step), seed 3030.
 
 No GPU and no reference needed: only the draws are stored, the expected numbers come from the oracle at test time."""
@@ -28,22 +28,24 @@ SPECIAL = [
 SPECIAL += [tuple(x) for x in json.load(open(os.path.join(HERE, "fuzz_special.json")))] if os.path.exists(os.path.join(HERE, "fuzz_special.json")) else []
 
 
-def case_at(seed, idx):
+def case_at(seed, idx, wide=False):
     rng = np.random.default_rng(seed)
     for i in range(idx + 1):
-        c = F.draw_case(rng, i)
-    c["origin"] = f"fuzz seed {seed}"
+        c = (F.draw_wide_case if wide else F.draw_case)(rng, i)
+    c["origin"] = f"{'wide' if wide else 'fuzz'} seed {seed}"
     return c
 
 
 def main():
     out = []
-    for seed, idx, why in SPECIAL:
-        c = case_at(seed, idx)
+    for entry in SPECIAL:
+        seed, idx, why = entry[:3]
+        c = case_at(seed, idx, wide=len(entry) > 3 and entry[3] == "wide")
         c["expect"], c["why"] = "set aside", why
         out.append(c)
     seen, rng, i = set(), np.random.default_rng(2026), 0
-    while len(out) < 64 and i < 5000:
+    n_spread = 61 + len(SPECIAL)                       # (61 + specials: a new special case does not push a spread case out)
+    while len(out) < n_spread and i < 5000:
         c = F.draw_case(rng, i)
         c["origin"] = "fuzz seed 2026"
         i += 1
@@ -55,7 +57,7 @@ def main():
             c["expect"] = "ok"
             out.append(c)
     rng, i = np.random.default_rng(2027), 0            # ... and plain draws of another seed up to 64
-    while len(out) < 64:
+    while len(out) < n_spread:
         c = F.draw_case(rng, i)
         c["origin"], c["expect"] = "fuzz seed 2027", "ok"
         i += 1
