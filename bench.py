@@ -39,8 +39,11 @@ import sys
 import time
 import types
 
-# dmabuf IPC (peer-mapped exchange buffers, RCCL): must be in the environment before the HIP runtime starts
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# dmabuf IPC for the peer-mapped exchange buffers of `--dp-exchange auto` (hipIpcGetMemHandle): must be in the environment
+# before the HIP runtime starts, so it is decided from argv here.  The default exchange is RCCL through torch.distributed,
+# which needs nothing from this script: the variable is then left exactly as the launcher's environment has it.
+if "auto" in [a_ for i_, a_ in enumerate(sys.argv) if i_ and sys.argv[i_ - 1] == "--dp-exchange"] or "--dp-exchange=auto" in sys.argv:
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -69,7 +72,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1600)
     ap.add_argument("--warmup", type=int, default=160)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"], help="bag STORAGE type; arithmetic is fp32")
+    ap.add_argument("--dtype", default="fp32", choices=["bf16", "fp16", "fp32"],
+                    help="bag STORAGE type; arithmetic is always fp32.  fp32 (default) is the storage of the reference's h5 "
+                         "embeddings and the one pinned end to end to the reference's main(); 16-bit storage moves the trained "
+                         "AUC by 0.001-0.03 (profiles/round3_storage_fidelity.jsonl), so it is reported as an extra block")
+    ap.add_argument("--no-16bit-extra", action="store_true", help="skip the bf16_storage extra block of a default fp32 run")
     ap.add_argument("--slides", type=int, default=32, help="train slides per epoch (NSCLC 16-shot: 32)")
     ap.add_argument("--patches", type=int, default=15000)
     ap.add_argument("--classes", type=int, default=2)
@@ -140,6 +147,8 @@ def workload_name(a):
     C = a.classes
     if C == 2 and a.slides == 32 and a.dim == 512:
         name = "NSCLC 2-way 16-shot"
+    elif C == 2 and a.slides == 2 and a.dim == 512:
+        name = "NSCLC 2-way 1-shot"
     elif C == 3 and a.slides == 48 and a.dim == 512:
         name = "RCC 3-way 16-shot"
     elif C == 30 and a.slides == 120 and a.dim == 512:
@@ -212,7 +221,7 @@ def main():
                                  pretrain="conch", ablation_study="none")
     all_sizes = synth.bag_sizes(99, a.slides, a.patches, fixed=not a.lognormal)
 
-    def make_split(mode):
+    def make_split(mode, store=store):
         """This rank's resident train split.  seq: the contiguous block [rank*per, (rank+1)*per) of the ONE task's
         slides (phase A shards, the recurrence does not); dp_strong: slide i of the ONE task lives on rank i mod world
         (step t consumes slides [t*world, (t+1)*world)); dp_weak / single: a whole task of its own per rank."""
@@ -236,6 +245,12 @@ def main():
         return m, torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4)
 
     def fence():
+        # (the host spins on an event of the main stream first: hipDeviceSynchronize's blocking wait wakes up 20-30 us
+        # after the GPU is done, 5 % of a 20-step region; the synchronize that follows then returns at once)
+        e = torch.cuda.Event()
+        e.record()
+        while not e.query():
+            pass
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -267,14 +282,16 @@ def main():
                 done += out[-1]
             return out
 
-        def run(self, lengths, then=None):
-            """Passes of the given lengths; `then` = length of the pass the caller runs next (None: nothing follows,
-            no phase A is issued ahead)."""
+        def run(self, lengths, then=None, then2=None):
+            """Passes of the given lengths; `then` / `then2` = lengths of the two passes the caller runs next (None:
+            nothing follows, no phase A is issued ahead / no masks are drawn ahead)."""
             res = self.res
+            upcoming = list(lengths) + [then, then2 if then is not None else None]
             for i, m in enumerate(lengths):
-                nxt = lengths[i + 1] if i + 1 < len(lengths) else then
+                nxt, nxt2 = upcoming[i + 1], upcoming[i + 2]
                 res.repeat_num = m if m < self.per_pass else None
                 res.next_pass_len = nxt if nxt is not None else 0      # 0: no pass follows
+                res.pass_after_next_len = nxt2 if nxt2 is not None else 0
                 t_in = time.perf_counter()
                 if self.mode == "seq":
                     mdist.train_seq(self.model, res, self.opt, dev, args)
@@ -283,9 +300,10 @@ def main():
                 else:
                     M.train(self.model, res, self.opt, dev, args)
                 if TRACE:
-                    print(f"trace: pass of {m} (next {nxt}) issued in {(time.perf_counter() - t_in) * 1e6:.0f} us", file=sys.stderr)
+                    print(f"trace: pass of {m} (next {nxt}, then {nxt2}) issued in {(time.perf_counter() - t_in) * 1e6:.0f} us", file=sys.stderr)
             res.repeat_num = None
             res.next_pass_len = None
+            res.pass_after_next_len = None
 
         def allocate(self, lengths):
             """Work arrays for every pass length that will occur: allocated here, not inside a timed region."""
@@ -315,29 +333,46 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         return bool(torch.equal(lo, hi)) and int(hi[2].item()) == 0
 
-    def measure(mode, n_steps, n_warm, steady_epochs):
+    def measure(mode, n_steps, n_warm, steady_epochs, store=store):
         """-> dict(value, dt, steady, loop, exchange, fallback) for one scaling mode.  The timed region is EXACTLY
         n_steps steps between two fences, after n_warm untimed steps of the same model."""
-        res = make_split(mode)
+        res = make_split(mode, store)
         model, opt = new_model()
         loop = Loop(res, model, opt, mode)
         units = world if mode in ("dp_strong", "dp_weak", "replicas") else 1     # slides one step consumes, over the whole job
         warm, timed = loop.schedule(n_warm), loop.schedule(n_steps)
         steady = [loop.per_pass] * steady_epochs
+        # The loop runs one pass ahead of itself: while the meta-steps of a pass run, phase A of the NEXT pass streams on
+        # the side stream (and the masks of the one after are drawn on the host).  A timed region of K steps therefore
+        # contains the phase A of whatever pass follows it -- so a pass as long as the region's last one follows it (the
+        # `spacer`, untimed): the region then issues phase A for exactly as many slides as it consumes, as every pass of
+        # a long run does.  (Before: the 32-slide phase A of the steady block trailed a 20-step region.)
+        spacer = [timed[-1]] if steady else []
         loop.allocate(warm + timed + steady)
         fallback = None
 
         def prime():
-            """Runtime warm-up that is not training: a throw-away meta-learner goes through a few passes of every
-            length that will occur, so that code objects, allocator pools, the side stream and the pass-ahead pipeline
-            exist before the W warm-up steps of the model that is measured (whatever W and K are)."""
-            m2, o2 = M.senet(D, 4).to(dev), None
-            o2 = torch.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=1e-4)
-            tmp = Loop(res, m2, o2, mode)
+            """Runtime warm-up that is not training: the meta-learner goes through passes of every length that will
+            occur -- twice each, once per set of work arrays -- so that code objects, allocator pools, the side stream, the
+            pass-ahead pipeline and the captured pass graphs (moc_train_steps_graph: keyed on the tensors of THIS model and
+            optimizer) exist; then its parameters and Adam state are put back, in place, to what they were.  The model
+            that is measured has afterwards taken exactly the W untimed and K timed steps, from its initial values."""
+            params = list(model.parameters())
+            saved = [p.detach().clone() for p in params]
+            tmp = Loop(res, model, opt, mode)
             seq = []
             for m in sorted(set(warm + timed + steady), reverse=True):
-                seq += [m] * (3 if m == loop.per_pass else 1)
+                seq += [m] * (4 if m == loop.per_pass else 2)
             tmp.run(seq + [loop.per_pass], then=(warm + timed)[0])
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for p, s0 in zip(params, saved):
+                    p.copy_(s0)
+                    st = opt.state[p]
+                    st["exp_avg"].zero_()
+                    st["exp_avg_sq"].zero_()
+                    st["step"].zero_()
+            torch.cuda.synchronize()
 
         # (the cyclic collector may not choose the 0.5-40 ms of a timed region for a full collection: one run in a few
         # dozen measured 11 ms for 100 steps that take 2.4.  Collected HERE, before the runtime warm-up -- a pause of
@@ -345,8 +380,9 @@ def main():
         # measured 23 k instead of 29 k -- and switched off until the regions are over.)
         gc.collect()
         gc.disable()
+        after_timed = (spacer + steady + [None, None])[:2]
         prime()
-        loop.run(warm, then=timed[0])
+        loop.run(warm, then=timed[0], then2=(timed + after_timed)[1])
         fence()
         exchange = getattr(mdist.train_dp, "exchange", None) if mode.startswith("dp") else None
         if world > 1 and mode != "replicas" and not ranks_agree(model):
@@ -361,16 +397,20 @@ def main():
             os.environ["MOC_DP_EXCHANGE"] = "rccl"
             model, opt = new_model()
             loop = Loop(res, model, opt, mode)
-            loop.run(warm, then=timed[0])
+            loop.run(warm, then=timed[0], then2=(timed + after_timed)[1])
             fence()
             exchange = mdist.train_dp.exchange
             assert ranks_agree(model), "ranks disagree on the collective path"
         if engine.SCORE_EVENTS is not None:
             engine.SCORE_EVENTS.clear()
         t0 = time.perf_counter()
-        loop.run(timed, then=(steady[0] if steady else None))
+        loop.run(timed, then=after_timed[0], then2=after_timed[1])
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
+        if TRACE and getattr(M.train, "trace_events", None):
+            for n_, e0_, e1_ in M.train.trace_events[-len(timed):]:
+                print(f"trace: timed pass of {n_}: GPU time between the pass's first launch and its last kernel {e0_.elapsed_time(e1_) * 1e3:.0f} us; "
+                      f"timed region {dt * 1e6:.0f} us", file=sys.stderr)
         ev = list(engine.SCORE_EVENTS) if engine.SCORE_EVENTS is not None else []
         assert mode == "replicas" or ranks_agree(model), "data-parallel ranks ended the timed region with different parameters"
         out = {"value": n_steps * units / dt, "dt": dt, "loop": loop, "exchange": exchange, "fallback": fallback,
@@ -378,6 +418,7 @@ def main():
         if steady:
             # the same model keeps training: whole epochs only, the pass-ahead pipeline in its periodic state
             engine_events, engine.SCORE_EVENTS = engine.SCORE_EVENTS, None
+            loop.run(spacer, then=steady[0], then2=steady[0])
             fence()
             t0 = time.perf_counter()
             loop.run(steady, then=None)
@@ -464,6 +505,27 @@ def main():
         roof["alone"] = {"achieved": round(iso_bytes / (iso_ms * 1e-3) / 1e9, 1),
                          "frac": round(iso_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launch_us": round(iso_ms * 1e3, 2),
                          "algorithmic_bytes": int(iso_bytes)}
+
+    # ---- the same loop on 16-bit copies of the bags (N = 1, default fp32 run): BASELINE configs[1] names bf16 storage,
+    # but the trained AUC does not stay within +-0.002 of the fp32 reference there, so it is an extra block, not `value`
+    half_block = None
+    if world == 1 and a.dtype == "fp32" and main_mode == "single" and not a.no_16bit_extra:
+        try:
+            ev_keep, engine.SCORE_EVENTS = engine.SCORE_EVENTS, None
+            rh = measure("single", a.steps, a.warmup, 0 if a.no_steady else min(20, a.steady_epochs), store=torch.bfloat16)
+            engine.SCORE_EVENTS = ev_keep
+            half_block = {"bag_storage": "bf16", "value": round(rh["value"], 1), "unit": "meta-steps/s", "steps": a.steps, "warmup": a.warmup,
+                          "steady_state": rh["steady"] and rh["steady"]["value"],
+                          "fidelity": "NOT the reference's numbers: from the same fp32 bags, bf16 storage moves a fixed model's pooled "
+                                      "logits by 1e-4..1e-2, per-epoch validation AUC by up to 0.06, test AUC at best val by "
+                                      "0.0006-0.03 over 9 tasks (fp16: 0.0005-0.04); evaluation of an untrained model stays within "
+                                      "5e-6 (loss) / equal AUC.  The sequential loop's own seed-to-seed spread on those tasks is "
+                                      "0.002-0.06 (std), so this is reseeding-sized noise -- but outside north_star's +-0.002 "
+                                      "(profiles/round3_storage_fidelity.jsonl, round3_dp_auc_control.jsonl)"}
+            rh["loop"] = rh["res"] = rh["model"] = None
+            del rh
+        except Exception as e:  # noqa: BLE001 -- an extra block must not cost the line its `value`
+            half_block = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- the modes that are not `value`, from shorter runs of this process, as extra keys (N > 1 only)
     extras = {}
@@ -552,35 +614,66 @@ def main():
                                "scripts/moc_train.sh packs five folds onto one GPU; moc_amd.run_many is its job queue.  One run is a "
                                "latency chain that leaves most of the GPU idle; independent runs interleave")
 
-    # ---- CPU baseline: the oracle's train loop on the host cores (rank 0, N=1 only)
+    # ---- CPU baseline: the oracle's train loop AND evaluation loop on the host cores (rank 0, N=1 only), a bounded
+    # sample of the same workload (slide-granular: wide configurations do not get through an epoch in the budget)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu and isinstance(res, M.ResidentBags):
+        import torch.nn.functional as F
         from oracle import moc_oracle as O
         labels = res.labels
         cpu_bags = [res.X[res.starts[i]:res.starts[i + 1]].to(torch.float32).cpu() for i in range(a.slides)]
         torch.manual_seed(0)
         cm = O.Senet(D, 4)
         co = O.make_optimizer(cm)
+
+        def cpu_train(ids):
+            O.train_epoch(cm, co, [cpu_bags[i] for i in ids], [labels[i] for i in ids], W, We, C, j, K)
+
+        def cpu_eval(ids):
+            """evaluation()'s per-slide work (main_moc.py:472-498); the metrics tail over [n, C] logits is left out"""
+            cm.eval()
+            with torch.no_grad():
+                for i in ids:
+                    sr = O.slide_process(cpu_bags[i], W, We, C, j)
+                    pooled = O.pool_top(O.mix_eval(cm(sr["selected_feat"]), sr, ()), [K])[1][K]
+                    F.cross_entropy(pooled, torch.as_tensor(labels[i]).view(1)).item()
+            cm.train()
+
         # pick the fastest intra-op thread count the quota allows (more is not faster: section 6 probes)
+        t0 = time.perf_counter()
+        cpu_train([0])
+        one = time.perf_counter() - t0                       # (first touch included: only sizes the calibration)
+        n_cal = 8 if one < 0.05 else 2
         best = None
         for th in sorted({1, 4, 8, 16, cpus} & set(range(1, cpus + 1))):
             torch.set_num_threads(th)
-            O.train_epoch(cm, co, cpu_bags[:2], labels[:2], W, We, C, j, K)      # warm-up at this width
+            cpu_train([0])                                   # warm-up at this width
             t0 = time.perf_counter()
-            O.train_epoch(cm, co, cpu_bags[:8], labels[:8], W, We, C, j, K)
-            rate = 8 / (time.perf_counter() - t0)
+            cpu_train([i % a.slides for i in range(n_cal)])
+            rate = n_cal / (time.perf_counter() - t0)
             if best is None or rate > best[1]:
                 best = (th, rate)
         threads = best[0]
         torch.set_num_threads(threads)
         n_done, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < a.cpu_seconds:
-            O.train_epoch(cm, co, cpu_bags, labels, W, We, C, j, K)
-            n_done += a.slides
+            cpu_train([n_done % a.slides])
+            n_done += 1
         cdt = time.perf_counter() - t0
+        n_ev, t0 = 0, time.perf_counter()
+        cpu_eval([0])
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < a.cpu_seconds / 2:
+            cpu_eval([n_ev % a.slides])
+            n_ev += 1
+        edt_cpu = time.perf_counter() - t0
         cpu = {"value": round(n_done / cdt, 2), "unit": "meta-steps/s", "cores": threads, "kind": "port",
-               "sample": f"{n_done} meta-steps = {n_done // a.slides} epochs of the same {a.slides} slides "
-                         f"(fp32 copies of the bag values, torch-CPU oracle, {threads} threads)"}
+               "eval_slides_per_sec": round(n_ev / edt_cpu, 2),
+               "sample": f"train: {n_done} meta-steps in {cdt:.1f} s over the run's own {a.slides} train slides in loader order "
+                         f"({n_done / a.slides:.2f} epochs; row mask on); eval: {n_ev} full-bag slides in {edt_cpu:.1f} s (the same "
+                         f"slides, no mask; evaluation()'s per-slide work, metrics tail left out); fp32 copies of the bag "
+                         f"values, torch-CPU oracle, {threads} threads"}
+        del cpu_bags
 
     if rank == 0:
         if world == 1 and main_mode != "seq":
@@ -606,6 +699,14 @@ def main():
             "eval_slides_per_sec": None if eval_rate is None else round(eval_rate, 1),
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if half_block:
+            out["bf16_storage"] = half_block
+        if world > 1:
+            out["ranks_seen"] = dist.get_world_size()
+            try:
+                out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:  # noqa: BLE001
+                out["rccl_version"] = f"unavailable ({type(e).__name__})"
         if replicas:
             out["replicas"] = replicas
         if packed:
@@ -621,6 +722,8 @@ def main():
             out["rehearsal"] = "all ranks on ONE device (MOC_BENCH_ONE_DEVICE=1): not a scaling measurement"
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+            if eval_rate is not None and cpu.get("eval_slides_per_sec"):
+                out["eval_speedup_vs_cpu_baseline"] = round(eval_rate / cpu["eval_slides_per_sec"], 1)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dp:

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 13
+#define MOC_ABI_VERSION 14
 
 enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
 
@@ -315,6 +315,29 @@ int moc_gated_attention_backward(const float* h, int64_t N, int L, const float* 
 int moc_train_steps(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
                     const int64_t* labels, int slide0, int n, uint32_t use_bits,
                     moc_stream_t stream);
+
+/* The same pass as ONE graph launch (main_moc.py:380-410: the whole `for data in train_loader` body, n slides).
+ * moc_train_steps issues 2 n + 1 kernel launches; at the start of a run -- or of a short timed region -- the stream is
+ * empty and the chain of 20-us meta-steps cannot run ahead of the host.  A `moc_step_graph_t` keeps each distinct pass
+ * (work arrays, meta-learner tensors, slide range) as an instantiated hipGraph and replays it with one call.  It is the
+ * second explicit handle of this ABI (after moc_p2p_t): it owns host-side state only -- the graphs, one pinned staging
+ * buffer, an event; the device memory it uses is the caller's `device_ws` (moc_step_graph_workspace_bytes(max_steps):
+ * a step counter + the Adam coefficients of the next max_steps steps, which the captured kernels read by position
+ * because kernel arguments are frozen at capture while the bias corrections change with every step).
+ *   - results are bit-identical to moc_train_steps (same kernels, same coefficient floats);
+ *   - all calls on one handle must be ordered on one stream (the counter lives in stream order);
+ *   - M->step is read on every call: if it is not where the handle left it (another optimizer stepped, a checkpoint
+ *     was loaded), the device counter is put right first; new hyper-parameters or an exhausted table rebuild the table;
+ *   - shapes outside the one-launch steps, n > max_steps, or a runtime that refuses capture / instantiation fall back
+ *     to moc_train_steps (moc_step_graph_stats tells which path ran).
+ * The caller advances M->step by n afterwards, as with moc_train_steps. */
+typedef struct moc_step_graph moc_step_graph_t;
+size_t moc_step_graph_workspace_bytes(int max_steps);
+int moc_step_graph_create(void* device_ws, size_t ws_bytes, moc_step_graph_t** out);
+int moc_step_graph_destroy(moc_step_graph_t* G);
+int moc_step_graph_stats(const moc_step_graph_t* G, int* captures, int* replays, int* eager_calls);
+int moc_train_steps_graph(moc_step_graph_t* G, const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
+                          const int64_t* labels, int slide0, int n, uint32_t use_bits, moc_stream_t stream);
 
 /* ---- generic pooling / ranking (a12, a17 and the index_* helpers) ----------
  * For each segment s (rows seg_off[s] .. seg_off[s+1]) and class c: rank rows by

@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 MOC_F32, MOC_BF16, MOC_F16 = 0, 1, 2
 SEL_BITS = {"topk": 1, "delta_softmax": 2, "delta_diff": 4, "bottomk": 8}
@@ -73,6 +73,11 @@ SIGNATURES = {
     "moc_train_grad": (C.c_int, [_BP, _MP, _WP, _p, C.c_int, C.c_uint32, _p]),
     "moc_adam_step": (C.c_int, [_MP, C.c_float, _p]),
     "moc_train_steps": (C.c_int, [_BP, _MP, _WP, _p, C.c_int, C.c_int, C.c_uint32, _p]),
+    "moc_step_graph_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "moc_step_graph_create": (C.c_int, [_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "moc_step_graph_destroy": (C.c_int, [_p]),
+    "moc_step_graph_stats": (C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "moc_train_steps_graph": (C.c_int, [_p, _BP, _MP, _WP, _p, C.c_int, C.c_int, C.c_uint32, _p]),
     "moc_train_steps_dp": (C.c_int, [_BP, _MP, _WP, _p, C.c_int, C.c_int, C.c_uint32, _p, C.c_int64, _p, _p,
                                      C.c_int, _p]),
     "moc_p2p_handle_bytes": (C.c_int, []),

@@ -16,6 +16,9 @@
 //   meta_forward (S/16 workgroups, f32 MFMA) -> topk_mean (C workgroups)
 //   -> finish (1 workgroup: CE, pair gradients, Adam on b1/W2/b2)
 //   -> w1_update (W1 gradient from <= K*C gathered rows + Adam, one thread per element)
+#include <cstdlib>
+#include <cstring>
+#include <new>
 #include "moc_common.h"
 #include <type_traits>
 #include "moc_p2p.h"
@@ -428,7 +431,20 @@ struct FinishArgs {
     int C, K, slide0, train, apply_adam;
     uint32_t use_bits;
     AdamCoef adam;
+    // graph replay (moc_train_steps_graph): the step's coefficients are adam_tab[adam_ctr[0] + adam_pos] instead of
+    // `adam` -- kernel arguments are frozen at capture, the Adam step count is not
+    const AdamCoef* adam_tab;
+    const int32_t* adam_ctr;
+    int adam_pos;
 };
+
+// the step's Adam coefficients: the kernel argument, or (graph replay) the table entry of this position in the pass.
+// Uniform addresses: two scalar loads, requested where this is called (kernel start), consumed at the very end.
+__device__ __forceinline__ AdamCoef step_coef(const FinishArgs& a) {
+    AdamCoef k = a.adam;
+    if (a.adam_tab) k = a.adam_tab[a.adam_ctr[0] + a.adam_pos];
+    return k;
+}
 
 constexpr int FIN_CHUNK = 256;   // pairs whose H1 rows are staged in LDS at a time (64 KiB)
 
@@ -929,6 +945,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
             }
         }
     float pW = 0.f, pM = 0.f, pV = 0.f;                  // workgroup 0: W2 / b2 / b1 element of this thread
+    const AdamCoef ak = step_coef(a);
     if (t < 4 * H) W2s[t] = a.W2[t];
     if (wg == 0 && a.apply_adam) {
         if (t < 4 * H) { pW = W2s[t]; pM = a.m_W2[t]; pV = a.v_W2[t]; }
@@ -1064,7 +1081,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
         if (tail >= 0) gt = p2p_sum(g.x, nW1 + tail, gt);
     }
     // ---- Adam: parameter, moments, operand image
-    const float gs = a.adam.grad_scale;
+    const float gs = ak.grad_scale;
     if (own) {
 #pragma unroll
         for (int sw = 0; sw < 2; ++sw) {
@@ -1073,7 +1090,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int e = (ha + j) * D + d;
-                    adam_update(pw[j][sw], pm[j][sw], pv[j][sw], gr[sw][j] * gs, a.adam);
+                    adam_update(pw[j][sw], pm[j][sw], pv[j][sw], gr[sw][j] * gs, ak);
                     g.W1[e] = pw[j][sw]; g.m_W1[e] = pm[j][sw]; g.v_W1[e] = pv[j][sw];
                     w1_image_store(g.img_dt, g.W1img, D, ha + j, d, pw[j][sw]);
                 }
@@ -1081,7 +1098,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
         }
     }
     if (tail >= 0) {                                      // workgroup 0: b1, W2 (into the other buffer), b2
-        adam_update(pW, pM, pV, gt * gs, a.adam);
+        adam_update(pW, pM, pV, gt * gs, ak);
         if (tail >= H + 4 * H) { const int i = tail - 5 * H; a.b2[i] = pW; a.m_b2[i] = pM; a.v_b2[i] = pV; }
         else if (tail >= H) { const int i = tail - H; g.W2out[i] = pW; a.m_W2[i] = pM; a.v_W2[i] = pV; }
         else { a.b1[tail] = pW; a.m_b1[tail] = pM; a.v_b1[tail] = pV; }
@@ -1145,6 +1162,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
             pw[i] = g.W1[e]; pm[i] = g.m_W1[e]; pv[i] = g.v_W1[e];
         }
     }
+    const AdamCoef ak = step_coef(a);
     if (t < 4 * H) W2s[t] = a.W2[t];
     // small tensors: threads 0..15 -> W2[i][4 wg + jj] (i = t >> 2, jj = t & 3); 16..19 -> b1[4 wg + jj]; 20..23 -> b2 (wg 0)
     float pS = 0.f, pSm = 0.f, pSv = 0.f;
@@ -1327,7 +1345,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     }
     MOC_STAMP(45);
     // ---- outputs
-    const float gs = a.adam.grad_scale;
+    const float gs = ak.grad_scale;
     float gv = 0.f;
     if (small >= 0) gv = t < 16 ? red[(t >> 2) * 4 + (t & 3)] : t < 20 ? red[16 + (t - 16)] : red[20 + (t - 20)];
     if (!a.apply_adam) {                                   // gradients out (data-parallel step with a collective)
@@ -1356,13 +1374,13 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int h = h0 + (lane >> 4) * 4 + i, d = d0 + (lane & 15), e = h * D + d;
-            adam_update(pw[i], pm[i], pv[i], gacc[i] * gs, a.adam);
+            adam_update(pw[i], pm[i], pv[i], gacc[i] * gs, ak);
             g.W1[e] = pw[i]; g.m_W1[e] = pm[i]; g.v_W1[e] = pv[i];
             w1_image_store(g.img_dt, g.W1img, D, h, d, pw[i]);
         }
     }
     if (small >= 0) {
-        adam_update(pS, pSm, pSv, gv * gs, a.adam);
+        adam_update(pS, pSm, pSv, gv * gs, ak);
         if (small >= 5 * H) { const int i = small - 5 * H; a.b2[i] = pS; a.m_b2[i] = pSm; a.v_b2[i] = pSv; }
         else if (small >= H) { const int i = small - H; g.W2out[i] = pS; a.m_W2[i] = pSm; a.v_W2[i] = pSv; }
         else { a.b1[small] = pS; a.m_b1[small] = pSm; a.v_b1[small] = pSv; }
@@ -1661,12 +1679,25 @@ int fused_step_mode(const moc_batch_t* B, const moc_meta_ws_t* ws) {
     return fused_step_ok(B, ws) ? 1 : fused_wide_ok(B, ws) ? 2 : 0;
 }
 
+// device-resident Adam coefficients for graph replay: the step's coefficients are tab[ctr[0] + pos]
+struct StepTab { const AdamCoef* tab; const int32_t* ctr; int pos; };
+
+void fused_step_attrs() {
+    // (outside any stream capture: raise the dynamic LDS limits of the two one-launch step kernels once)
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute((const void*)pool_w1_step_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
+    (void)hipFuncSetAttribute((const void*)pool_w1_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
+    done = true;
+}
+
 int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels,
                       int slide, uint32_t use_bits, const AdamCoef& k, float* W2out, hipStream_t s,
-                      int apply_adam = 1, const P2pArgs* x = nullptr) {
+                      int apply_adam = 1, const P2pArgs* x = nullptr, const StepTab* tab = nullptr) {
     FusedArgs g = {};
     if (x) g.x = *x;
     FinishArgs& a = g.f;
+    if (tab) { a.adam_tab = tab->tab; a.adam_ctr = tab->ctr; a.adam_pos = tab->pos; }
     a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel; a.cand = B->cand;
     a.H1 = ws->H1; a.gates = ws->gates; a.pooled = ws->pooled; a.mixed_in = ws->mixed;
     a.labels = labels; a.loss = ws->loss; a.pred = ws->pred;
@@ -1898,6 +1929,12 @@ extern "C" int moc_train_steps_p2p(const moc_batch_t* B, const moc_meta_t* M, co
     return MOC_OK;
 }
 
+struct moc_step_graph;
+namespace {
+int issue_fused_pass(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels,
+                     int slide0, int n, uint32_t use_bits, hipStream_t s, const moc_step_graph* G);
+}
+
 extern "C" int moc_train_steps(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
                                const int64_t* labels, int slide0, int n, uint32_t use_bits,
                                moc_stream_t stream) {
@@ -1905,27 +1942,8 @@ extern "C" int moc_train_steps(const moc_batch_t* B, const moc_meta_t* M, const 
     if (int rc = check_meta(B, M, ws, "moc_train_steps", true, false)) return rc;
     MOC_REQUIRE(labels && slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_train_steps: bad labels/slide range");
     hipStream_t s = (hipStream_t)stream;
+    if (fused_step_mode(B, ws)) return issue_fused_pass(B, M, ws, labels, slide0, n, use_bits, s, nullptr);
     if (int rc = launch_w1_image(B, M, s)) return rc;      // afterwards the W1 update keeps it in sync
-    if (fused_step_mode(B, ws)) {
-        // two launches per meta-step: forward, then pooling + loss + backward + the whole Adam step.
-        // W2 is read by every workgroup of the second kernel while workgroup 0 steps it: ping-pong.
-        moc_meta_t Mt = *M;
-        float* cur = M->W2;
-        float* nxt = ws->W2_alt;
-        for (int t = 0; t < n; ++t) {
-            const int b = slide0 + t;
-            const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f);
-            Mt.W2 = cur;
-            if (int rc = launch_forward(B, &Mt, ws, b, 1, use_bits, s)) return rc;
-            if (int rc = launch_fused_step(B, &Mt, ws, labels, b, use_bits, k, nxt, s)) return rc;
-            float* tmp = cur; cur = nxt; nxt = tmp;
-        }
-        if (cur != M->W2) {   // odd number of steps: the current W2 lives in the scratch buffer
-            if (hipMemcpyAsync(M->W2, cur, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, s) != hipSuccess)
-                MOC_FAIL(MOC_ELAUNCH, "moc_train_steps: copy-back of W2 failed");
-        }
-        return MOC_OK;
-    }
     for (int t = 0; t < n; ++t) {
         const int b = slide0 + t;
         const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f);
@@ -1933,6 +1951,269 @@ extern "C" int moc_train_steps(const moc_batch_t* B, const moc_meta_t* M, const 
         if (int rc = launch_pool_finish(B, M, ws, labels, b, 1, 1, 1, use_bits, k, s)) return rc;
         if (int rc = launch_w1(B, M, ws, 1, k, s, fused_ok(B, 1))) return rc;
     }
+    return MOC_OK;
+}
+
+// ------------------------------------------------------------------ a pass of meta-steps as ONE graph launch
+// moc_train_steps issues 2 n + 1 launches per pass (0.2 ms of host time for 32 steps).  In a long run they are
+// issued ahead of the GPU and cost nothing; at the START of a run, or of a short timed region, the queue is empty and
+// the chain cannot begin before the host has got through its prelude.  The handle below keeps the pass as an
+// instantiated hipGraph per (work arrays, meta-learner tensors, slide range): a replay is one hipGraphLaunch.
+// What changes from replay to replay -- the Adam step count, i.e. the bias corrections -- is not a kernel argument
+// there: the coefficients of steps tab_base + 1 ... tab_base + cap sit in a device table (computed by the host with
+// the arithmetic of adam_coef, so the same floats as the eager path) and a device counter holds how many of them have
+// been used; the kernel at position t of the pass reads entry ctr + t, the graph's last node advances ctr by n.
+struct moc_step_graph {
+    int32_t* ctr;            // device: steps taken since tab_base (caller's workspace, first 16 bytes)
+    AdamCoef* tab;           // device [cap]: entry i = coefficients of step tab_base + i + 1
+    int cap;
+    // host mirror
+    bool tab_valid;
+    double lr, beta1, beta2, eps, wd;
+    int64_t tab_base;
+    int64_t dev_rel;         // the counter's value once everything issued so far has run (-1: unknown)
+    AdamCoef* stage;         // pinned staging of the table upload
+    hipEvent_t stage_done;   // the upload that read `stage` has run
+    bool stage_busy;
+    hipStream_t cap_stream;  // passes are captured here (nothing ever runs on it): the caller's stream may be the
+                             // legacy default stream, which cannot be captured
+    struct Entry {
+        unsigned char key[512];
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        uint64_t used;
+    } e[8];
+    int n_entries;
+    uint64_t tick;
+    int eager_only;          // capture or instantiation failed once: the handle stays on stream launches
+    int captures, replays, eager_calls;
+};
+
+namespace {
+
+__global__ void step_ctr_set_kernel(int32_t* ctr, int32_t v) { ctr[0] = v; }
+__global__ void step_ctr_add_kernel(int32_t* ctr, int32_t n) { ctr[0] += n; }
+
+struct GraphKey {            // everything a captured pass bakes into its kernel arguments
+    const void *X, *row_off, *sel_row, *n_sel, *cand, *labels;
+    const void *W1, *b1, *W2, *b2, *mW1, *mb1, *mW2, *mb2, *vW1, *vb1, *vW2, *vb2, *img;
+    const void *H1, *gates, *mixed, *pooled, *topk_idx, *topk_cnt, *loss, *pred, *pair_dh, *W2_alt, *pair_row, *n_pair;
+    int64_t total_rows;
+    uint64_t off_hash;       // FNV-1a of row_off_host[slide0 .. slide0 + n]
+    int32_t dtype, D, n_slides, C, topk, s_bound, mode, external, slide0, n;
+    uint32_t use_bits;
+};
+static_assert(sizeof(GraphKey) <= 512, "GraphKey outgrew moc_step_graph::Entry::key");
+
+void graph_key(GraphKey* k, const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels,
+               int slide0, int n, uint32_t use_bits, int mode) {
+    memset(k, 0, sizeof(*k));
+    k->X = B->X; k->row_off = B->row_off; k->sel_row = B->sel_row; k->n_sel = B->n_sel; k->cand = B->cand; k->labels = labels;
+    k->W1 = M->W1; k->b1 = M->b1; k->W2 = M->W2; k->b2 = M->b2; k->mW1 = M->m_W1; k->mb1 = M->m_b1; k->mW2 = M->m_W2;
+    k->mb2 = M->m_b2; k->vW1 = M->v_W1; k->vb1 = M->v_b1; k->vW2 = M->v_W2; k->vb2 = M->v_b2; k->img = M->W1_image;
+    k->H1 = ws->H1; k->gates = ws->gates; k->mixed = ws->mixed; k->pooled = ws->pooled; k->topk_idx = ws->topk_idx;
+    k->topk_cnt = ws->topk_cnt; k->loss = ws->loss; k->pred = ws->pred; k->pair_dh = ws->pair_dh; k->W2_alt = ws->W2_alt;
+    k->pair_row = ws->pair_row; k->n_pair = ws->n_pair;
+    k->total_rows = B->total_rows;
+    uint64_t h = 1469598103934665603ull;
+    if (B->row_off_host)
+        for (int i = slide0; i <= slide0 + n; ++i) { h ^= (uint64_t)B->row_off_host[i]; h *= 1099511628211ull; }
+    k->off_hash = B->row_off_host ? h : 0;
+    k->dtype = B->dtype; k->D = B->D; k->n_slides = B->n_slides; k->C = B->C; k->topk = B->topk; k->s_bound = s_bound(B);
+    k->mode = mode;
+    k->external = mode == 2 && (s_bound(B) > 8192 || (int64_t)B->C * s_bound(B) > 49152);
+    k->slide0 = slide0; k->n = n; k->use_bits = use_bits;
+}
+
+// the 2 n + 1 launches of a fused-step pass; `tab` != null: coefficients from the device table (capture)
+int issue_fused_pass(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels,
+                     int slide0, int n, uint32_t use_bits, hipStream_t s, const moc_step_graph* G) {
+    if (int rc = launch_w1_image(B, M, s)) return rc;      // afterwards the W1 update keeps it in sync
+    // two launches per meta-step: forward, then pooling + loss + backward + the whole Adam step.
+    // W2 is read by every workgroup of the second kernel while workgroup 0 steps it: ping-pong.
+    moc_meta_t Mt = *M;
+    float* cur = M->W2;
+    float* nxt = ws->W2_alt;
+    for (int t = 0; t < n; ++t) {
+        const int b = slide0 + t;
+        AdamCoef k = {};
+        StepTab st = {};
+        if (G) { st.tab = G->tab; st.ctr = G->ctr; st.pos = t; }
+        else k = adam_coef(M, M->step + 1 + t, 1.f);
+        Mt.W2 = cur;
+        if (int rc = launch_forward(B, &Mt, ws, b, 1, use_bits, s)) return rc;
+        if (int rc = launch_fused_step(B, &Mt, ws, labels, b, use_bits, k, nxt, s, 1, nullptr, G ? &st : nullptr)) return rc;
+        float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (cur != M->W2) {   // odd number of steps: the current W2 lives in the scratch buffer
+        if (hipMemcpyAsync(M->W2, cur, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            MOC_FAIL(MOC_ELAUNCH, "moc_train_steps: copy-back of W2 failed");
+    }
+    if (G) {
+        step_ctr_add_kernel<<<1, 1, 0, s>>>(G->ctr, n);
+        MOC_CHECK_LAUNCH("moc_step_ctr_add");
+    }
+    return MOC_OK;
+}
+
+}  // namespace
+
+extern "C" size_t moc_step_graph_workspace_bytes(int max_steps) {
+    return max_steps > 0 ? 16 + sizeof(AdamCoef) * (size_t)max_steps : 0;
+}
+
+extern "C" int moc_step_graph_create(void* device_ws, size_t ws_bytes, moc_step_graph_t** out) {
+    MOC_REQUIRE(out && device_ws && ((uintptr_t)device_ws & 15) == 0, "moc_step_graph_create: null or unaligned workspace");
+    MOC_REQUIRE(ws_bytes >= 16 + sizeof(AdamCoef) * 64, "moc_step_graph_create: workspace of %zu bytes holds fewer than 64 steps", ws_bytes);
+    moc_step_graph* G = new (std::nothrow) moc_step_graph();
+    MOC_REQUIRE(G, "moc_step_graph_create: out of host memory");
+    memset(G, 0, sizeof(*G));
+    G->ctr = (int32_t*)device_ws;
+    G->tab = (AdamCoef*)((unsigned char*)device_ws + 16);
+    G->cap = (int)((ws_bytes - 16) / sizeof(AdamCoef));
+    G->dev_rel = -1;
+    if (hipHostMalloc((void**)&G->stage, sizeof(AdamCoef) * (size_t)G->cap, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&G->stage_done, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&G->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+        if (G->stage) (void)hipHostFree(G->stage);
+        delete G;
+        MOC_FAIL(MOC_ELAUNCH, "moc_step_graph_create: cannot allocate the pinned staging buffer");
+    }
+    *out = G;
+    return MOC_OK;
+}
+
+extern "C" int moc_step_graph_destroy(moc_step_graph_t* G) {
+    if (!G) return MOC_OK;
+    for (int i = 0; i < G->n_entries; ++i) {
+        (void)hipGraphExecDestroy(G->e[i].exec);
+        (void)hipGraphDestroy(G->e[i].graph);
+    }
+    if (G->stage_busy) (void)hipEventSynchronize(G->stage_done);
+    (void)hipEventDestroy(G->stage_done);
+    (void)hipStreamDestroy(G->cap_stream);
+    (void)hipHostFree(G->stage);
+    delete G;
+    return MOC_OK;
+}
+
+extern "C" int moc_step_graph_stats(const moc_step_graph_t* G, int* captures, int* replays, int* eager_calls) {
+    MOC_REQUIRE(G, "moc_step_graph_stats: null handle");
+    if (captures) *captures = G->captures;
+    if (replays) *replays = G->replays;
+    if (eager_calls) *eager_calls = G->eager_calls;
+    return MOC_OK;
+}
+
+extern "C" int moc_train_steps_graph(moc_step_graph_t* G, const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
+                                     const int64_t* labels, int slide0, int n, uint32_t use_bits, moc_stream_t stream) {
+    MOC_REQUIRE(G, "moc_train_steps_graph: null handle");
+    if (int rc = moc_check_batch(B, "moc_train_steps_graph")) return rc;
+    if (int rc = check_meta(B, M, ws, "moc_train_steps_graph", true, false)) return rc;
+    MOC_REQUIRE(labels && slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_train_steps_graph: bad labels/slide range");
+    hipStream_t s = (hipStream_t)stream;
+    // Grids and kernel shapes follow B->max_rows, which a masked batch tightens to the largest KEPT-row count of the
+    // pass (moc_host_max_kept): a different number every pass.  A captured pass must not depend on it, so the graph is
+    // built for the largest SLIDE of the range -- an upper bound of every pass's kept rows (surplus workgroups leave at
+    // once on n_sel).
+    moc_batch_t Bg = *B;
+    if (B->row_off_host) {
+        int64_t mx = 1;
+        for (int i = slide0; i < slide0 + n; ++i) {
+            const int64_t r = B->row_off_host[i + 1] - B->row_off_host[i];
+            if (r > mx) mx = r;
+        }
+        Bg.max_rows = (int32_t)(mx < 0x7fffffff ? mx : 0x7fffffff);
+    }
+    const moc_batch_t* Bo = B;     // as handed in: for the stream-launch fall-back
+    B = &Bg;
+    const int mode = fused_step_mode(B, ws);
+    if (!mode || G->eager_only || n > G->cap) {            // shapes of the three-launch step, or a handle that gave up
+        G->eager_calls++;
+        G->dev_rel = -1;
+        return moc_train_steps(Bo, M, ws, labels, slide0, n, use_bits, stream);
+    }
+    fused_step_attrs();
+    // ---- the coefficient table covers steps M->step + 1 ... M->step + n with these hyper-parameters?
+    const bool same_hp = G->tab_valid && G->lr == M->lr && G->beta1 == M->beta1 && G->beta2 == M->beta2 &&
+                         G->eps == M->eps && G->wd == M->weight_decay;
+    if (!same_hp || M->step < G->tab_base || M->step + n > G->tab_base + G->cap) {
+        if (G->stage_busy) {                               // the previous upload still owns the staging buffer
+            if (hipEventSynchronize(G->stage_done) != hipSuccess) MOC_FAIL(MOC_ELAUNCH, "moc_train_steps_graph: staging event");
+            G->stage_busy = false;
+        }
+        for (int i = 0; i < G->cap; ++i) G->stage[i] = adam_coef(M, M->step + 1 + i, 1.f);
+        if (hipMemcpyAsync(G->tab, G->stage, sizeof(AdamCoef) * (size_t)G->cap, hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipEventRecord(G->stage_done, s) != hipSuccess)
+            MOC_FAIL(MOC_ELAUNCH, "moc_train_steps_graph: upload of the coefficient table failed");
+        G->stage_busy = true;
+        G->tab_valid = true;
+        G->lr = M->lr; G->beta1 = M->beta1; G->beta2 = M->beta2; G->eps = M->eps; G->wd = M->weight_decay;
+        G->tab_base = M->step;
+        G->dev_rel = -1;
+    }
+    // ---- the device counter stands where this optimizer's step count is?  (someone else may have stepped it, or a
+    // checkpoint was loaded: one tiny launch puts it right, value by kernel argument)
+    const int64_t rel = M->step - G->tab_base;
+    if (G->dev_rel != rel) {
+        step_ctr_set_kernel<<<1, 1, 0, s>>>(G->ctr, (int32_t)rel);
+        MOC_CHECK_LAUNCH("moc_step_ctr_set");
+        G->dev_rel = rel;
+    }
+    {   // diagnostic: the table-reading kernels as plain stream launches (separates what the table costs from what the graph costs)
+        static const char* mode_env = getenv("MOC_STEP_GRAPH_MODE");
+        if (mode_env && strcmp(mode_env, "table") == 0) {
+            if (int rc = issue_fused_pass(B, M, ws, labels, slide0, n, use_bits, s, G)) return rc;
+            G->eager_calls++;
+            G->dev_rel = rel + n;
+            return MOC_OK;
+        }
+    }
+    // ---- find or capture the pass
+    GraphKey key;
+    graph_key(&key, B, M, ws, labels, slide0, n, use_bits, mode);
+    moc_step_graph::Entry* hit = nullptr;
+    for (int i = 0; i < G->n_entries; ++i)
+        if (memcmp(G->e[i].key, &key, sizeof(key)) == 0) { hit = &G->e[i]; break; }
+    if (!hit) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        int rc = MOC_OK;
+        hipError_t he = hipStreamBeginCapture(G->cap_stream, hipStreamCaptureModeRelaxed);
+        if (he != hipSuccess) rc = MOC_ELAUNCH;
+        else {
+            rc = issue_fused_pass(B, M, ws, labels, slide0, n, use_bits, G->cap_stream, G);
+            he = hipStreamEndCapture(G->cap_stream, &graph);          // (always: leaves the stream out of capture mode)
+            if (rc == MOC_OK && (he != hipSuccess || !graph)) rc = MOC_ELAUNCH;
+        }
+        if (rc == MOC_OK && (he = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0)) != hipSuccess) rc = MOC_ELAUNCH;
+        if (rc != MOC_OK) {                                // no graph on this runtime: stream launches from now on
+            moc_set_error("moc_train_steps_graph: capture / instantiation failed (%s); falling back to stream launches",
+                          hipGetErrorString(he));
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            G->eager_only = 1;
+            G->eager_calls++;
+            G->dev_rel = -1;
+            return moc_train_steps(Bo, M, ws, labels, slide0, n, use_bits, stream);
+        }
+        if (G->n_entries < 8) hit = &G->e[G->n_entries++];
+        else {                                             // replace the entry that was used longest ago
+            hit = &G->e[0];
+            for (int i = 1; i < 8; ++i) if (G->e[i].used < hit->used) hit = &G->e[i];
+            (void)hipGraphExecDestroy(hit->exec);
+            (void)hipGraphDestroy(hit->graph);
+        }
+        memset(hit->key, 0, sizeof(hit->key));
+        memcpy(hit->key, &key, sizeof(key));
+        hit->graph = graph;
+        hit->exec = exec;
+        G->captures++;
+    }
+    hit->used = ++G->tick;
+    if (hipGraphLaunch(hit->exec, s) != hipSuccess) MOC_FAIL(MOC_ELAUNCH, "moc_train_steps_graph: hipGraphLaunch failed");
+    G->replays++;
+    G->dev_rel = rel + n;
     return MOC_OK;
 }
 

@@ -724,7 +724,7 @@ def train_seq(model, shard: SeqShardedBags, optimizer, device, args, group=None)
         if after is not None:
             torch.set_rng_state(after)
     cb = plan["sets"][plan["turn"]]["compact"]
-    meta = engine.MetaState(model, optimizer)
+    meta = engine.MetaState.cached(model, optimizer)
     engine.train_steps(cb, meta, plan["labels"], 0, m, use)
     train_seq.last = (cb, plan["labels"])
     train_seq.last_local = plan["sets"][plan["turn"]]["local"]

@@ -6,6 +6,8 @@ device buffers and the stream; every kernel is ours.
 from __future__ import annotations
 
 import ctypes as C
+import os
+import weakref
 from typing import Sequence
 
 import torch
@@ -14,6 +16,13 @@ from . import _lib
 from ._lib import MocBatch, MocMeta, MocMetaWs, check, lib, ptr
 
 HIDDEN = 64
+# MOC_STEP_GRAPH=1: a pass of meta-steps as one hipGraph launch (moc_train_steps_graph) instead of 2 n + 1 stream
+# launches (moc_train_steps).  Bit-identical (tests/test_gpu_graph.py) and it frees the host (38 against 170-250 us per
+# 32-step pass), but on the GPU the replayed chain is 1-3 % SLOWER than the stream launches (fp32 bags: 27.7 against
+# 26.9 us per step; steady state 36.6 k against 37.0 k meta-steps/s, bf16 42.5 k against 43.4 k) and its first kernel
+# starts later (the whole graph is enqueued before the doorbell), so stream launches stay the default.
+STEP_GRAPH = os.environ.get("MOC_STEP_GRAPH", "0") == "1"
+GRAPH_TABLE_STEPS = 4096        # Adam steps of coefficients kept on the device per table build
 
 # bench.py sets this to a list: every batched score-pass launch then appends
 # (start_event, stop_event, algorithmic_bytes) recorded on the launch stream.
@@ -254,6 +263,7 @@ class MetaState:
             assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous(), "senet must be fp32 on the GPU"
         self.D = lin1.in_features
         self.optimizer = optimizer
+        self._group, self._graph, self._graph_ws, self._graph_ok = None, None, None, False
         kw = dict(lr=0.0, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, H=HIDDEN, D=self.D, step=0)
         names = ("W1", "b1", "W2", "b2")
         ptrs = {n: ptr(p.data) for n, p in zip(names, self.params)}
@@ -262,7 +272,7 @@ class MetaState:
             assert isinstance(optimizer, torch.optim.Adam), "the fused step implements torch.optim.Adam only"
             groups = [g for g in optimizer.param_groups if any(p is q for p in g["params"] for q in self.params)]
             assert len(groups) == 1, "senet parameters must sit in one param group"
-            g = groups[0]
+            g = self._group = groups[0]
             assert not g.get("amsgrad", False) and not g.get("maximize", False), "amsgrad/maximize unsupported"
             steps = set()
             for n, p in zip(names, self.params):
@@ -287,6 +297,64 @@ class MetaState:
                                     dtype=torch.uint8, device=self.params[0].device)
         ptrs["W1_image"] = ptr(self.w1_image)
         self.c = MocMeta(**ptrs, **kw)
+
+    # ---- one MetaState per (model, optimizer), reused from pass to pass: building the views costs 20-40 us of
+    # Python, and the pass graphs (moc_train_steps_graph) are keyed on the tensors it points at
+    _cache = weakref.WeakKeyDictionary()
+
+    @classmethod
+    def cached(cls, model, optimizer):
+        ent = cls._cache.get(model)
+        if ent is not None:
+            meta, opt_ref, sig = ent
+            if opt_ref() is optimizer and sig == cls._signature(meta.params, optimizer):
+                meta.refresh()
+                return meta
+        meta = cls(model, optimizer)
+        meta._graph_ok = True          # lives from pass to pass: worth capturing its passes
+        cls._cache[model] = (meta, weakref.ref(optimizer), cls._signature(meta.params, optimizer))
+        return meta
+
+    @staticmethod
+    def _signature(params, optimizer):
+        sig = []
+        for p in params:
+            st = optimizer.state.get(p) or {}
+            sig.append((p.data_ptr(), id(st.get("exp_avg")), id(st.get("exp_avg_sq")), id(st.get("step"))))
+        return tuple(sig)
+
+    def refresh(self):
+        """Hyper-parameters and step count as the optimizer holds them NOW (someone may have changed the learning
+        rate, stepped it, or loaded a state dict in place)."""
+        g = self._group
+        b1, b2 = g["betas"]
+        c = self.c
+        c.lr, c.beta1, c.beta2, c.eps, c.weight_decay = float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"])
+        steps = {int(float(self.optimizer.state[p]["step"])) for p in self.params}
+        assert len(steps) == 1, "parameters disagree on the Adam step count"
+        c.step = steps.pop()
+
+    def step_graph(self):
+        """The moc_step_graph_t of this meta-learner (created on first use).  None when switched off, and for a
+        MetaState built for one call (not through `cached`): its graphs would be captured and thrown away."""
+        if not (STEP_GRAPH and self._graph_ok):
+            return None
+        if self._graph is None:
+            nbytes = lib().moc_step_graph_workspace_bytes(GRAPH_TABLE_STEPS)
+            self._graph_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.params[0].device)
+            h = C.c_void_p()
+            check(lib().moc_step_graph_create(ptr(self._graph_ws), nbytes, C.byref(h)), "moc_step_graph_create")
+            self._graph = h
+            weakref.finalize(self, lib().moc_step_graph_destroy, h).atexit = False   # (at exit the runtime goes first)
+        return self._graph
+
+    def graph_stats(self):
+        """(captures, replays, passes that fell back to stream launches) of this meta-learner's pass graphs."""
+        if self._graph is None:
+            return (0, 0, 0)
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(lib().moc_step_graph_stats(self._graph, C.byref(a), C.byref(b), C.byref(c)), "moc_step_graph_stats")
+        return a.value, b.value, c.value
 
     def advance(self, n_steps: int):
         """Record n fused Adam steps in the optimizer's own step counters."""
@@ -372,9 +440,10 @@ class MaskDrawer:
                 return i
         raise AssertionError("MaskDrawer: no buffer")
 
-    def take(self, state_before: torch.Tensor):
+    def take(self, state_before: torch.Tensor, chain: bool = True):
         """-> (pinned flags, kept rows, max kept rows of a slide, generator state after, buffer index) or None when
-        the generator state is not the layout the replay knows (the caller lets torch draw)."""
+        the generator state is not the layout the replay knows (the caller lets torch draw).  `chain` False: the pass
+        after this one has another row layout (the caller starts ITS drawer): nothing is drawn ahead here."""
         if torch.get_default_dtype() != torch.float32:
             return None
         got = None
@@ -392,9 +461,9 @@ class MaskDrawer:
                 return None
             got = (i, res)
         i, (kept, mk, st_after) = got
-        # the flags of the pass after this one, in the background
-        j = self._free_buffer(exclude=(i,))
-        self.ahead = (st_after, j, self.pool.submit(self._draw, st_after, j))
+        if chain:                                 # the flags of the pass after this one, in the background
+            j = self._free_buffer(exclude=(i,))
+            self.ahead = (st_after, j, self.pool.submit(self._draw, st_after, j))
         return self.bufs[i], kept, mk, st_after, i
 
     def prefetch(self, state_before: torch.Tensor):
@@ -455,10 +524,17 @@ def loss_only(batch: SlideBatch, labels: torch.Tensor, slide0: int, n: int):
 
 
 def train_steps(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, slide0: int, n: int, use_bits: int):
-    """n consecutive meta-steps (one slide each) with Adam applied in place."""
+    """n consecutive meta-steps (one slide each) with Adam applied in place: one graph launch per pass when the
+    meta-learner has a step graph (MOC_STEP_GRAPH, default on), 2 n + 1 stream launches otherwise -- same kernels,
+    same coefficient floats, bit-identical parameters."""
     _, ws = batch.meta_ws()
-    check(lib().moc_train_steps(C.byref(batch.c), C.byref(meta.c), C.byref(ws), ptr(labels), slide0, n,
-                                use_bits, _stream()), "moc_train_steps")
+    g = meta.step_graph()
+    if g is not None:
+        check(lib().moc_train_steps_graph(g, C.byref(batch.c), C.byref(meta.c), C.byref(ws), ptr(labels), slide0, n,
+                                          use_bits, _stream()), "moc_train_steps_graph")
+    else:
+        check(lib().moc_train_steps(C.byref(batch.c), C.byref(meta.c), C.byref(ws), ptr(labels), slide0, n,
+                                    use_bits, _stream()), "moc_train_steps")
     meta.advance(n)
 
 

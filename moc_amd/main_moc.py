@@ -123,6 +123,7 @@ class ResidentBags:
         # reference's mask stream exactly; phase A is then not issued a pass ahead (module docstring)
         self.loader_seed_draw = bool(loader_seed_draw)
         self.next_pass_len = None          # see resident_pass_done
+        self.pass_after_next_len = None    # ... and the one after that, when it differs (mask draws run two passes ahead)
         self.X, self.sizes = _pack(bags, device, dtype)
         self.labels = [int(v) for v in labels]
         self.repeat_num = repeat_num
@@ -275,14 +276,18 @@ MASK_AHEAD = os.environ.get("MOC_MASK_AHEAD", "1") != "0"   # keep flags drawn a
 _TRACE = os.environ.get("MOC_BENCH_TRACE") == "1"          # host time of train()'s four parts on stderr (diagnostic)
 
 
-def _issue_phase_a(plan, turn, bank, rng_before, host_wait=None):
+def _issue_phase_a(plan, turn, bank, rng_before, host_wait=None, chain_plan=None):
     """Draw the masks that follow generator state `rng_before` (main_moc.py:330: same stream of bits),
-    upload them and run phase A into work-array set `turn` on the CURRENT stream.
+    upload them and run phase A into work-array set `turn` on the CURRENT stream.  `chain_plan`: the plan of the pass
+    AFTER the one these masks are for, when it visits other rows (its drawer then starts on the flags that follow).
     -> generator state after the draws (None: the state's layout is unknown, torch drew and advanced itself)."""
     batch = plan["batches"][turn]
-    drawn = plan["drawer"].take(rng_before) if MASK_AHEAD else None    # usually ready: drawn a pass ahead on the helper thread
+    same = chain_plan is None or chain_plan is plan
+    drawn = plan["drawer"].take(rng_before, chain=same) if MASK_AHEAD else None    # usually ready: drawn a pass ahead on the helper thread
     if drawn is not None:
         stage, kept, max_kept, rng_after, buf = drawn
+        if not same:
+            chain_plan["drawer"].prefetch(rng_after)
     else:                                               # generator layout unknown to the replay: torch draws, in line
         if plan["stage_free"][turn] is not None:
             plan["stage_free"][turn].synchronize()      # the phase A that read that pinned buffer has run
@@ -330,21 +335,19 @@ def _resident_pass_setup(res, device, args):
         if after is not None:
             torch.set_rng_state(after)
     plan["batch"] = plan["batches"][plan["turn"]]
-    if PREFETCH_PHASE_A and not res.loader_seed_draw:
-        # the generator now stands where the NEXT pass's draws start: let the helper thread draw them beside this
-        # pass's kernel launches (a no-op when it is already drawing exactly that)
-        nplan = _next_plan(res, plan, bank, args)
-        if nplan is not None and MASK_AHEAD:
-            nplan["drawer"].prefetch(torch.get_rng_state())
     return plan["batch"], lab, bank
 
 
-def _next_plan(res, plan, bank, args):
+def _next_plan(res, plan, bank, args, which="next_pass_len"):
     """The plan of the pass that follows this one: the same visits (the reference's epoch loop), or what the caller
-    announced in `res.next_pass_len` (0: no pass follows -> None)."""
-    hint = getattr(res, "next_pass_len", None)
+    announced in `res.next_pass_len` (0: no pass follows -> None).  which="pass_after_next_len": the pass after that."""
+    hint = getattr(res, which, None)
     if hint == 0:
         return None
+    if hint is None and which != "next_pass_len":
+        hint = getattr(res, "next_pass_len", None)       # (not announced: as the next one)
+        if hint == 0:
+            return None
     if hint is None or hint == len(res):
         return plan
     keep, res.repeat_num = res.repeat_num, (hint if hint != res.real_len() else None)
@@ -383,8 +386,10 @@ def resident_pass_done(res, device, args):
     # The HOST waits for that mark, not the side stream: a stream-side wait on an event of the main stream
     # cost ~45 us of GPU time per pass here (scripts/diag_overlap.py: 0.76 ms per epoch against 0.72), and
     # the host is a pass ahead with this pass's launches already queued, so its wait starves nothing.
+    chain = _next_plan(res, plan, bank, args, which="pass_after_next_len")
     with torch.cuda.stream(side):
-        after = _issue_phase_a(nplan, other, bank, before, host_wait=nplan.setdefault("steps_done", [None, None])[other])
+        after = _issue_phase_a(nplan, other, bank, before, host_wait=nplan.setdefault("steps_done", [None, None])[other],
+                               chain_plan=chain)
         done = torch.cuda.Event()
         done.record(side)
     if after is None:                                   # torch drew for us and moved its generator: undo, no speculation
@@ -405,11 +410,15 @@ def train(model, train_loader, optimizer, device, args):
         batch, lab, bank = _resident_pass_setup(train_loader, device, args)      # phase A issued (or adopted)
         if _TRACE:
             t1 = time.perf_counter()
-        meta = MetaState(model, optimizer)
+        meta = MetaState.cached(model, optimizer)
         if _TRACE:
             t2 = time.perf_counter()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         engine.train_steps(batch, meta, lab, 0, batch.n_slides, use)
         if _TRACE:
+            ev1.record()
+            train.trace_events = getattr(train, "trace_events", [])[-200:] + [(batch.n_slides, ev0, ev1)]
             t3 = time.perf_counter()
         resident_pass_done(train_loader, device, args)
         if _TRACE:

@@ -1,8 +1,10 @@
 """Phase stamps of gated_attention_kernel (workgroup 0) from the diagnostic build
-(make -C moc_amd/csrc stamps; MOC_HIP_LIB=moc_amd/libmoc_hip_stamps.so)."""
+(make -C moc_amd/csrc stamps; built into build/ by scripts/_stamps.py)."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("MOC_HIP_LIB", os.path.join(ROOT, "moc_amd", "libmoc_hip_stamps.so"))
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _stamps  # noqa: E402,F401  (builds build/libmoc_hip_stamps.so here if missing; sets MOC_HIP_LIB)
 import torch
 sys.path.insert(0, ROOT)
 from moc_amd import engine

@@ -1,5 +1,5 @@
 """Where one wave of the streaming score kernel (three n-tiles) spends its cycles -- diagnostic build
-(make -C moc_amd/csrc stamps; MOC_HIP_LIB=moc_amd/libmoc_hip_stamps.so): locate + issue / wait for loads / LDS reads +
+(make -C moc_amd/csrc stamps; built into build/ by scripts/_stamps.py): locate + issue / wait for loads / LDS reads +
 MFMAs / row epilogue, summed over the units of wave 0 of workgroup 0.
 
     python scripts/diag_score_phases.py [classes 30] [dim 512] [slides 120] [rows 15000] [masked 1]
@@ -9,7 +9,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("MOC_HIP_LIB", os.path.join(ROOT, "moc_amd", "libmoc_hip_stamps.so"))
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _stamps  # noqa: E402,F401  (builds build/libmoc_hip_stamps.so here if missing; sets MOC_HIP_LIB)
 import torch  # noqa: E402
 
 sys.path.insert(0, ROOT)

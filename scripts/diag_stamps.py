@@ -1,7 +1,9 @@
 """Where a meta-step spends its microseconds: phase stamps from the diagnostic build
-(make -C moc_amd/csrc stamps; MOC_HIP_LIB=moc_amd/libmoc_hip_stamps.so).  Shares, not totals."""
+(make -C moc_amd/csrc stamps; built into build/ by scripts/_stamps.py).  Shares, not totals."""
 import os, sys, ctypes as C
-os.environ.setdefault("MOC_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "moc_amd", "libmoc_hip_stamps.so"))
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _stamps  # noqa: E402,F401  (builds build/libmoc_hip_stamps.so here if missing; sets MOC_HIP_LIB)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 torch.set_num_threads(8)

@@ -28,9 +28,11 @@ sys.path.insert(0, ROOT)
 from moc_amd import dist as mdist, main_moc as M, synth  # noqa: E402
 
 
-def run(task, G, lr, epochs=25):
+def run(task, G, lr, epochs=25, reseed=0):
+    """`reseed` != 0: another (initialisation, mask stream) pair for the SAME task data -- the reference seeds neither
+    (main_moc.py:315, :330), so two of its own runs differ exactly like this."""
     dev = torch.device("cuda:0")
-    C, j, K, seed = task["C"], task["j"], task["K"], task["seed"]
+    C, j, K, seed = task["C"], task["j"], task["K"], task["seed"] + 7777 * reseed
     M.set_classifier_bank(task["W"].to(dev), task["We"].to(dev))
     args = types.SimpleNamespace(disable_tqdm=True, n_classes=C, topj=j, topk=K, discard_classifiers=[],
                                  pretrain="conch", ablation_study="none")
@@ -82,10 +84,34 @@ def nsclc_task(seed, n=(32, 64, 202), mean_rows=2500, confusion=0.47, gain=0.12)
             "C": C, "j": j, "K": K, "seed": seed, "W": W, "We": We, "loaders": loaders, "reference": None}
 
 
+def control(tasks, n_seeds=5):
+    """The control the minibatch study lacked: the SEQUENTIAL loop's own run-to-run spread
+    over (init, mask) seeds, per task; G = 2 / 4 / 8 at the same seeds beside it, learning rate as is."""
+    for task in tasks:
+        rows = {G: [run(task, G, 1e-3, reseed=k) for k in range(n_seeds)] for G in (1, 2, 4, 8)}
+        out = {"control": True, "task": task["name"], "seeds": n_seeds}
+        for G, rs in rows.items():
+            bv = np.array([r["best_val"] for r in rs])
+            ta = np.array([r["test_at_best_val"] for r in rs])
+            out[f"G{G}"] = {"best_val": [round(float(v), 4) for v in bv], "test_at_best_val": [round(float(v), 4) for v in ta],
+                            "best_val_range": round(float(bv.max() - bv.min()), 4), "test_range": round(float(ta.max() - ta.min()), 4),
+                            "best_val_mean": round(float(bv.mean()), 4), "test_mean": round(float(ta.mean()), 4),
+                            "best_val_std": round(float(bv.std(ddof=1)), 4), "test_std": round(float(ta.std(ddof=1)), 4)}
+        # paired differences at equal seeds: minibatch minus sequential
+        for G in (2, 4, 8):
+            d = np.array([rows[G][k]["test_at_best_val"] - rows[1][k]["test_at_best_val"] for k in range(n_seeds)])
+            out[f"G{G}"]["paired_d_test_mean"] = round(float(d.mean()), 4)
+            out[f"G{G}"]["paired_d_test_max_abs"] = round(float(np.abs(d).max()), 4)
+        print(json.dumps(out), flush=True)
+
+
 def main():
     tasks = ([fixture_task(0), fixture_task(1)] + [nsclc_task(s) for s in (31000, 31001)] +
              [nsclc_task(s, confusion=0.40, gain=0.16) for s in (31010, 31011)] +
              [nsclc_task(s, confusion=0.30, gain=0.20) for s in (31020, 31021)])
+    if "--control" in sys.argv:
+        control(tasks)
+        return
     for task in tasks:
         base = run(task, 1, 1e-3)
         print(json.dumps({"task": task["name"], "G": 1, "lr": 1e-3, **base, "reference_main": task["reference"]}), flush=True)

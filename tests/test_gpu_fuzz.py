@@ -35,11 +35,13 @@ def test_committed_cases_agree_or_are_set_aside_by_the_committed_classifier(gpu_
         if c["_grad_check"] != "compared":
             print("GRADIENT CHECK SKIPPED", F.describe(c), "--", c["_grad_check"])
         if r != "ok":
-            aside.append((F.describe(c), r[1]))
+            aside.append((F.describe(c), r[1], c.get("expect", "ok")))
             print("SET ASIDE", F.describe(c), "--", r[1])
         else:
             assert c.get("expect", "ok") in ("ok", "set aside")
-    # a chunk of 8 may hold the known undefined cases (they are listed first), never a crowd
+    # only the cases the committed list marks as undefined (`expect: set aside`, listed first) may be set aside: a case
+    # the list expects to agree and the classifier excuses anyway is a failure, not a quiet green
     known = sum(1 for c in CASES[lo:lo + CHUNK] if c.get("expect") == "set aside")
-    assert len(aside) <= max(1, known), aside
+    unknown = [a for a in aside if a[2] != "set aside"]
+    assert not unknown and len(aside) <= known, aside
     assert compared >= len(CASES[lo:lo + CHUNK]) - 2 - known, f"only {compared} of the chunk's cases had their gradients compared element-wise"
