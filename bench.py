@@ -226,8 +226,7 @@ def main():
         slides (phase A shards, the recurrence does not); dp_strong: slide i of the ONE task lives on rank i mod world
         (step t consumes slides [t*world, (t+1)*world)); dp_weak / single: a whole task of its own per rank."""
         if mode == "seq":
-            per = (a.slides + world - 1) // world
-            ids = list(range(min(a.slides, rank * per), min(a.slides, (rank + 1) * per)))
+            ids = mdist.block_lists(a.slides, world)[rank]          # contiguous, balanced
             bags = [synth.make_bag_device(1234 + i, all_sizes[i], D, We, C, i % C, dev, store) for i in ids]
             return mdist.SeqShardedBags(bags, all_sizes, [i % C for i in range(a.slides)], dev, rank, world)
         if mode == "dp_strong" and world > 1:
@@ -680,8 +679,8 @@ def main():
             par = "single GPU, one Adam step per slide"
         elif main_mode == "seq":
             par = (f"seq{world}: exact-sequential -- bags and phase A (mask, scores, selectors, union) sharded over the {world} GPUs "
-                   f"in contiguous blocks of {(a.slides + world - 1) // world} slides, compact results all-gathered (RCCL) a pass "
-                   "ahead, every rank runs the one-Adam-step-per-slide recurrence: bit-identical to one GPU")
+                   f"in contiguous balanced blocks of {a.slides // world}-{(a.slides + world - 1) // world} slides, unpadded compact results "
+                   "all-gathered (RCCL) a pass ahead, every rank runs the one-Adam-step-per-slide recurrence: bit-identical to one GPU")
         else:
             how = ("inside the step kernel (peer-mapped xGMI buffers)" if exchange == "p2p" else "by one RCCL all-reduce")
             par = (f"dp{world}: one slide per rank per synchronous step, 33,092-float meta-gradient summed over the ranks {how}; "

@@ -199,6 +199,14 @@ int moc_phase_a(const moc_batch_t* B, const void* bank, moc_stream_t stream);
 int moc_pack_selected(const moc_batch_t* B, int slide0, int n, int cap, void* feat_out, float* cand_out,
                       moc_stream_t stream);
 
+/* The same hand-over without padding, for a gather of unequal pieces: slide slide0+b's min(n_sel, cap) rows start at
+ * row sum_{q<b} min(n_sel[slide0+q], cap) of feat_out (device [out_rows][D], X's dtype), and its candidate scores are
+ * the rows cand_out[that row + t][2C+2] (device fp32, ROW-major: s_p[C] | s_sigma[C] | s_delta | s_beta per selected
+ * row -- main_moc.py:359-366's four matrices side by side); rows at and beyond out_rows are dropped.  What the
+ * exact-sequential mode sends since round 3: sum S rows per rank instead of n x cap (44 % less at NSCLC-16). */
+int moc_pack_selected_rows(const moc_batch_t* B, int slide0, int n, int cap, void* feat_out, float* cand_out,
+                           int64_t out_rows, moc_stream_t stream);
+
 /* ---- phase B: meta-learner, pooling, loss, update ------------------------- */
 
 /* use_bits: which of the four gated terms enter the sum (bit i = term i).

@@ -66,6 +66,7 @@ SIGNATURES = {
     "moc_gather_candidates": (C.c_int, [_BP, _p, _p]),
     "moc_phase_a": (C.c_int, [_BP, _p, _p]),
     "moc_pack_selected": (C.c_int, [_BP, C.c_int, C.c_int, C.c_int, _p, _p, _p]),
+    "moc_pack_selected_rows": (C.c_int, [_BP, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int64, _p]),
     "moc_meta_forward": (C.c_int, [_BP, _MP, _WP, C.c_int, C.c_int, C.c_uint32, _p]),
     "moc_mix_fixed": (C.c_int, [_BP, _WP, C.c_int, C.c_int, C.c_int, _p]),
     "moc_pool_loss": (C.c_int, [_BP, _WP, _p, C.c_int, C.c_int, _p]),

@@ -269,21 +269,45 @@ struct PackArgs {
     unsigned char* feat_out;
     float* cand_out;
     int64_t stride;
-    int row_bytes, C, cap, slide0;
+    int64_t out_rows;       // packed form: rows the outputs hold
+    int row_bytes, C, cap, slide0, packed;
 };
 
+// packed != 0: no padding -- slide slide0+y's rows start at row sum_{q<y} min(n_sel[slide0+q], cap) of feat_out
+// [sum S][D], and its candidate scores are the ROWS cand_out[that row + t][2C+2] (row-major: what an all-gather of
+// unequal pieces can carry; the receiver transposes).
 __global__ __launch_bounds__(256) void pack_selected_kernel(PackArgs a) {
     const int y = blockIdx.y, b = a.slide0 + y;
     const int64_t base = a.row_off[b];
     const int S = min(a.n_sel[b], a.cap);
+    if (blockIdx.x * 16 >= S) return;
+    __shared__ int64_t pref_s;
+    int64_t pref = (int64_t)y * a.cap;
+    if (a.packed) {
+        if (threadIdx.x < 64) {                           // one wave sums the y counts in front of this slide
+            int64_t part = 0;
+            for (int q = threadIdx.x; q < y; q += 64) part += min(a.n_sel[a.slide0 + q], a.cap);
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            if (threadIdx.x == 0) pref_s = part;
+        }
+        __syncthreads();
+        pref = pref_s;
+    }
     const int vec_per_row = a.row_bytes / 16;
     const int s = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (s < S) {
+    if (s < S && (!a.packed || pref + s < a.out_rows)) {
         const uint4* src = reinterpret_cast<const uint4*>(a.X + a.sel_row[base + s] * (int64_t)a.row_bytes);
-        uint4* dst = reinterpret_cast<uint4*>(a.feat_out + ((int64_t)y * a.cap + s) * a.row_bytes);
+        uint4* dst = reinterpret_cast<uint4*>(a.feat_out + (pref + s) * a.row_bytes);
         for (int v = threadIdx.x & 15; v < vec_per_row; v += 16) dst[v] = src[v];
     }
     const int nk = 2 * a.C + 2;
+    if (a.packed) {
+        for (int e = threadIdx.x; e < nk * 16; e += 256) {
+            const int t = blockIdx.x * 16 + e / nk, k = e - (e / nk) * nk;      // consecutive threads: consecutive floats of a row
+            if (t < S && pref + t < a.out_rows) a.cand_out[(pref + t) * nk + k] = a.cand[(int64_t)k * a.stride + base + t];
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < nk * 16; e += 256) {
         const int k = e >> 4, t = blockIdx.x * 16 + (e & 15);
         if (t < S) a.cand_out[((int64_t)y * nk + k) * a.cap + t] = a.cand[(int64_t)k * a.stride + base + t];
@@ -547,8 +571,25 @@ extern "C" int moc_pack_selected(const moc_batch_t* B, int slide0, int n, int ca
     a.X = (const unsigned char*)B->X; a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel; a.cand = B->cand;
     a.feat_out = (unsigned char*)feat_out; a.cand_out = cand_out; a.stride = B->total_rows;
     a.row_bytes = B->D * moc_elem_size(B->dtype); a.C = B->C; a.cap = cap; a.slide0 = slide0;
+    a.packed = 0; a.out_rows = 0;
     pack_selected_kernel<<<dim3(moc_cdiv(cap, 16), n), 256, 0, (hipStream_t)stream>>>(a);
     MOC_CHECK_LAUNCH("moc_pack_selected");
+    return MOC_OK;
+}
+
+extern "C" int moc_pack_selected_rows(const moc_batch_t* B, int slide0, int n, int cap, void* feat_out, float* cand_out,
+                                      int64_t out_rows, moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_pack_selected_rows")) return rc;
+    MOC_REQUIRE(B->sel_row && B->n_sel && B->cand, "moc_pack_selected_rows: batch has no phase-A outputs");
+    MOC_REQUIRE(slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_pack_selected_rows: bad slide range");
+    MOC_REQUIRE(cap >= 1 && out_rows >= 1 && feat_out && cand_out, "moc_pack_selected_rows: bad cap/outputs");
+    PackArgs a;
+    a.X = (const unsigned char*)B->X; a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel; a.cand = B->cand;
+    a.feat_out = (unsigned char*)feat_out; a.cand_out = cand_out; a.stride = B->total_rows;
+    a.row_bytes = B->D * moc_elem_size(B->dtype); a.C = B->C; a.cap = cap; a.slide0 = slide0;
+    a.packed = 1; a.out_rows = out_rows;
+    pack_selected_kernel<<<dim3(moc_cdiv(cap, 16), n), 256, 0, (hipStream_t)stream>>>(a);
+    MOC_CHECK_LAUNCH("moc_pack_selected_rows");
     return MOC_OK;
 }
 

@@ -175,6 +175,9 @@ def to_sharded(split: Generic_Split, device, rank: int, world: int, dtype=None, 
     from . import dist as mdist
     n = split.real_len()
     labels = [int(v) for v in split.slide_data["label"]]
+    if train and world > n:               # from (n, world) alone: the same on every rank, before anything collective
+        raise ValueError(f"exact-sequential training: the train split has {n} slide(s) but the job has {world} ranks -- "
+                         f"every rank must hold at least one slide; run with at most {n} rank(s)")
     blocks = mdist.block_lists(n, world)
     bags, paths = [], []
     for i in blocks[rank]:

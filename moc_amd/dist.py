@@ -61,38 +61,88 @@ class DirectRccl:
     def __init__(self, device, group=None):
         import ctypes as C
         import os
+        import warnings
         self.C = C
         self.ok = False
         self.comm = C.c_void_p()
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.why = ""
+
+        def agree(mine_ok: bool) -> bool:
+            """Collective: True only when EVERY rank got through the stage just finished.  A rank that failed still
+            joins every agreement, so nobody is left waiting in a collective its peer skipped."""
+            flag = torch.tensor([1 if mine_ok else 0], dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return int(flag.item()) == 1
+
+        class UniqueId(C.Structure):                          # ncclUniqueId: 128 opaque bytes, passed BY VALUE
+            _fields_ = [("internal", C.c_byte * 128)]
+
+        # stage 1 (not collective): the library and its symbols
+        good = True
         try:
-            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            path = os.environ.get("MOC_RCCL_LIB") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
             self.lib = C.CDLL(path)
-            class UniqueId(C.Structure):                      # ncclUniqueId: 128 opaque bytes, passed BY VALUE
-                _fields_ = [("internal", C.c_byte * 128)]
-            uid = UniqueId()
-            if self.rank == 0:
-                assert self.lib.ncclGetUniqueId(C.byref(uid)) == 0
-            box = [bytes(uid)]
-            dist.broadcast_object_list(box, src=0, group=group)
-            uid = UniqueId.from_buffer_copy(box[0])
             self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
             self.lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            self.lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        except Exception as e:  # noqa: BLE001  (set-up only; the data path never swallows errors)
+            good, self.why = False, f"rank {self.rank}: librccl: {e}"
+        if not agree(good):
+            warnings.warn(f"direct RCCL unavailable ({self.why or 'on another rank'}); using torch.distributed.all_reduce")
+            return
+        # stage 2: the unique id travels through torch.distributed (every rank takes part, whatever rank 0 got)
+        uid = UniqueId()
+        if self.rank == 0:
+            try:
+                good = self.lib.ncclGetUniqueId(C.byref(uid)) == 0
+            except Exception as e:  # noqa: BLE001
+                good, self.why = False, f"ncclGetUniqueId: {e}"
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        uid = UniqueId.from_buffer_copy(box[0])
+        if not agree(good):
+            warnings.warn(f"direct RCCL unavailable ({self.why or 'rank 0 got no unique id'}); using torch.distributed.all_reduce")
+            return
+        # stage 3 (collective inside RCCL: every rank is here, all agreed so far)
+        try:
             torch.cuda.set_device(device)
             rc = self.lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank)
-            assert rc == 0, f"ncclCommInitRank rc={rc}"
-            # self-check against torch's collective on a known vector
+            good = rc == 0
+            if not good:
+                self.why = f"rank {self.rank}: ncclCommInitRank rc={rc}"
+        except Exception as e:  # noqa: BLE001
+            good, self.why = False, f"rank {self.rank}: ncclCommInitRank: {e}"
+        if not agree(good):
+            warnings.warn(f"direct RCCL unavailable ({self.why or 'communicator failed on another rank'}); using torch.distributed.all_reduce")
+            self._destroy_comm()
+            return
+        # stage 4: self-check against torch's collective on a known vector (both collectives on every rank)
+        try:
             a = torch.arange(1, 1025, dtype=torch.float32, device=device) * (self.rank + 1)
             b = a.clone()
             self.all_reduce_(a)
             dist.all_reduce(b, group=group)
             torch.cuda.synchronize()
-            assert torch.equal(a, b), "direct RCCL all-reduce disagrees with torch.distributed"
-            self.ok = True
-        except Exception as e:  # noqa: BLE001  (set-up only; the data path never swallows errors)
-            import warnings
-            warnings.warn(f"direct RCCL unavailable ({e}); using torch.distributed.all_reduce")
+            good = bool(torch.equal(a, b))
+            if not good:
+                self.why = f"rank {self.rank}: direct RCCL all-reduce disagrees with torch.distributed"
+        except Exception as e:  # noqa: BLE001
+            good, self.why = False, f"rank {self.rank}: self-check: {e}"
+        self.ok = agree(good)
+        if not self.ok:
+            warnings.warn(f"direct RCCL unavailable ({self.why or 'self-check failed on another rank'}); using torch.distributed.all_reduce")
+            self._destroy_comm()
+
+    def _destroy_comm(self):
+        try:
+            if self.comm:
+                self.lib.ncclCommDestroy.argtypes = [self.C.c_void_p]
+                self.lib.ncclCommDestroy(self.comm)
+        except Exception:  # noqa: BLE001
+            pass
+        self.comm = self.C.c_void_p()
 
     def all_reduce_(self, flat: torch.Tensor):
         rc = self.lib.ncclAllReduce(flat.data_ptr(), flat.data_ptr(), flat.numel(), self.NCCL_FLOAT32, self.NCCL_SUM,
@@ -465,9 +515,35 @@ def train_dp(model, loader, optimizer, device, args, group=None):
 
 # --------------------------------------------------------------------------- splits spread over the ranks
 def block_lists(n_items: int, world: int):
-    """Contiguous blocks of the loader order, one per rank (the last ones may be short or empty)."""
-    per = (n_items + world - 1) // world
-    return [list(range(min(n_items, r * per), min(n_items, (r + 1) * per))) for r in range(world)]
+    """Contiguous blocks of the loader order, one per rank, BALANCED: n // world items each and one more on the first
+    n % world ranks, so no rank is empty unless world > n (ceil-sized blocks left trailing ranks empty: 12 slides on
+    8 ranks gave 2, 2, 2, 2, 2, 2, 0, 0)."""
+    base, extra = divmod(n_items, world)
+    out, lo = [], 0
+    for r in range(world):
+        k = base + (1 if r < extra else 0)
+        out.append(list(range(lo, lo + k)))
+        lo += k
+    return out
+
+
+def seq_layout(counts_by_rank):
+    """Where the gathered pieces of a pass land.  counts_by_rank[r] = n_sel of rank r's slides of this pass, in loader
+    order.  Every rank sends `mx` rows (its own sum S, padded to the largest sum of any rank); rank r's piece starts at
+    row r * mx of the gathered array, its slides back to back inside it.  -> (mx, row_off over ALL slides in loader
+    order + the end, n_sel in loader order).  Pure: the same on every rank, testable without a GPU."""
+    totals = [int(sum(c)) for c in counts_by_rank]
+    mx = max(1, max(totals) if totals else 1)
+    row_off, n_sel = [], []
+    for r, cs in enumerate(counts_by_rank):
+        o = r * mx
+        for c in cs:
+            assert int(c) >= 1, "a slide of the pass selected no row"
+            row_off.append(o)
+            n_sel.append(int(c))
+            o += int(c)
+    row_off.append(row_off[-1] + n_sel[-1] if n_sel else 0)
+    return mx, row_off, n_sel
 
 
 class ShardedSplit:
@@ -542,19 +618,26 @@ def ablation_evaluation(split: ShardedSplit, device, args, group=None):
 
 # --------------------------------------------------------------------------- exact-sequential multi-GPU (section 8e mode 1)
 class SeqShardedBags(ShardedSplit):
-    """A train split whose slides live on G GPUs -- rank r holds the contiguous block [r*per, (r+1)*per) of the
-    loader order -- for train_seq.  Every rank knows every slide's size and label (the mask stream and the labels
-    are global); only the bag rows are sharded.  Being a ShardedSplit it can also be evaluated (main_moc.py:615
-    evaluates the train split every epoch)."""
+    """A train split whose slides live on G GPUs -- rank r holds the r-th contiguous block of the loader order
+    (block_lists: balanced) -- for train_seq.  Every rank knows every slide's size and label (the mask stream and the
+    labels are global); only the bag rows are sharded.  Being a ShardedSplit it can also be evaluated (main_moc.py:615
+    evaluates the train split every epoch).
+
+    More ranks than slides cannot work (a rank with no bag has no phase A to contribute and no bank dtype to go by):
+    that is decided from (n, world) alone, so EVERY rank raises the same ValueError here, before any collective."""
 
     def __init__(self, my_bags, all_sizes, all_labels, device, rank: int, world: int, dtype=None, paths=None):
         self.all_sizes = [int(v) for v in all_sizes]
         n = len(self.all_sizes)
         assert len(all_labels) == n and n >= 1
         self.rank, self.world = int(rank), int(world)
-        self.per = (n + world - 1) // world
+        if world > n:
+            raise ValueError(f"exact-sequential training: the train split has {n} slide(s) but the job has {world} ranks -- "
+                             f"every rank must hold at least one slide; run with at most {n} rank(s)")
         blocks = block_lists(n, world)
-        self.lo, self.hi = min(n, rank * self.per), min(n, (rank + 1) * self.per)
+        self.blocks = blocks
+        self.per = max(len(b_) for b_ in blocks)                 # slides of the fullest rank
+        self.lo, self.hi = blocks[rank][0], blocks[rank][-1] + 1
         assert len(my_bags) == self.hi - self.lo, f"rank {rank} holds slides [{self.lo}, {self.hi}) of the loader order"
         assert [int(b.size(0)) for b in my_bags] == self.all_sizes[self.lo:self.hi]
         super().__init__(my_bags, blocks[rank], all_labels, blocks, device, dtype=dtype, paths=paths)
@@ -572,13 +655,17 @@ def _seq_plan(sh: SeqShardedBags, m: int, bank, args):
         return plan
     assert m <= sh.real_len()                                   # (longer passes are split into rounds by train_seq)
     dev, per, world = sh.device, sh.per, sh.world
-    n_loc = max(0, min(m, sh.hi) - sh.lo)                       # this rank's slides among the pass's first m visits
+    # the slides of this pass (the first m of the loader order) that each rank holds
+    n_by_rank = [max(0, min(m, blk[-1] + 1) - blk[0]) for blk in sh.blocks]
+    n_loc = n_by_rank[sh.rank]
     cap = min(args.topj * (2 * bank.C + 2), max(sh.all_sizes))  # a slide selects at most this many rows
+    nk = 2 * bank.C + 2
     starts = [0]
     for v in sh.all_sizes:
         starts.append(starts[-1] + v)
     X = sh.local.X if sh.local is not None else None
     dtype, D = bank.dtype, bank.D
+    pin = (lambda t: t.pin_memory()) if torch.device(dev).type == "cuda" else (lambda t: t)
     sets = []
     for _ in range(2):
         local = None
@@ -586,31 +673,43 @@ def _seq_plan(sh: SeqShardedBags, m: int, bank, args):
             sizes = sh.local.sizes[:n_loc]
             local = SlideBatch(X, sizes, bank.C, bank.Ce, args.topj, args.topk, args.discard_classifiers,
                                mask=torch.ones(sum(sizes), dtype=torch.uint8), x_starts=sh.local.starts[:n_loc])
+        # what this rank sends: its slides' selected rows back to back (moc_pack_selected_rows), at most per * cap of them
+        send_feat = torch.zeros((per * cap, D), dtype=dtype, device=dev)
+        # what every rank ends up with: world pieces of `mx` rows each (mx = the pass's largest per-rank sum, known
+        # once the counts have been exchanged); at world 1 the piece IS the send buffer -- nothing is copied
+        recv_feat = send_feat if world == 1 else torch.zeros((world * per * cap, D), dtype=dtype, device=dev)
         sets.append({
             "local": local,
-            "send_feat": torch.zeros((per * cap, D), dtype=dtype, device=dev),
-            "send_cand": torch.zeros((per, 2 * bank.C + 2, cap), dtype=torch.float32, device=dev),
+            "send_feat": send_feat,
+            "send_cand": torch.zeros((per * cap, nk), dtype=torch.float32, device=dev),
             "send_nsel": torch.zeros(per, dtype=torch.int32, device=dev),
-            "compact": CompactBatch(per * world, cap, D, dtype, bank.C, bank.Ce, args.topj, args.topk, dev),
+            "all_nsel": torch.zeros(world * per, dtype=torch.int32, device=dev),
+            "nsel_host": pin(torch.zeros(world * per, dtype=torch.int32)),
+            "recv_cand": torch.zeros((world * per * cap, nk), dtype=torch.float32, device=dev),
+            "compact": CompactBatch(m, world * per * cap, cap, D, dtype, bank.C, bank.Ce, args.topj, args.topk, dev, X=recv_feat),
             "stage": torch.empty(max(1, starts[min(m, sh.hi)] - starts[sh.lo]) if n_loc else 1, dtype=torch.uint8).pin_memory(),
             "stage_free": None, "steps_done": None,
         })
     side = torch.cuda.Stream(device=dev)
     for st in sets:
-        ts = [st["send_feat"], st["send_cand"], st["send_nsel"], st["compact"].X, st["compact"].cand,
-              st["compact"].cand_blocks, st["compact"].n_sel]
+        cb = st["compact"]
+        ts = [st["send_feat"], st["send_cand"], st["send_nsel"], st["all_nsel"], st["recv_cand"], cb.X, cb.cand, cb.n_sel, cb.row_off]
         if st["local"] is not None:
             b = st["local"]
             ts += [t for t in (b.kept, b.n_kept, b.stats, b.sel_flag, b.sel_idx, b.sel_row, b.n_sel, b.cand, b.row_off, b.x_off) if t is not None]
             X.record_stream(side)
         for t in ts:
             t.record_stream(side)
+    # position of (rank r, local slide i) in the gathered count vector, for the pass's slides in loader order
+    order = [r * per + i for r in range(world) for i in range(n_by_rank[r])]
     plan = sh._plans[key] = {
-        "sets": sets, "turn": 0, "ahead": None, "side": side, "m": m, "n_loc": n_loc, "cap": cap,
+        "sets": sets, "turn": 0, "ahead": None, "side": side, "m": m, "n_loc": n_loc, "n_by_rank": n_by_rank, "cap": cap,
         "row_lo": starts[sh.lo], "row_hi": starts[min(m, sh.hi)] if n_loc else starts[sh.lo], "rows_total": starts[m],
-        "labels": torch.tensor(sh.all_labels[:m] + [0] * (per * world - m), dtype=torch.int64).to(dev),
+        "labels": torch.tensor(sh.all_labels[:m], dtype=torch.int64).to(dev),
+        "order": torch.tensor(order, dtype=torch.int64).to(dev),
         "all_masks": torch.empty(starts[m], dtype=torch.uint8),
         "drawer": engine.MaskDrawer(starts[m], (ctypes.c_int64 * (m + 1))(*starts[:m + 1]), m),
+        "sent_rows": 0, "padded_rows": 0,                       # statistics: rows this rank sent / would have sent in cap-sized blocks
     }
     return plan
 
@@ -626,10 +725,40 @@ def _all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None):
     dist.all_gather([parts[q] for q in range(world)], inp, group=group)
 
 
+def seq_exchange(st, n_by_rank, per, world, group=None, sync=None):
+    """The hand-over of a pass (collective): counts first, then the UNPADDED pieces.  `st` holds this rank's packed
+    selections (`send_feat` [.., D], `send_cand` [.., 2C+2] row-major, `send_nsel` [per]) and the receive side
+    (`all_nsel` [world * per], `nsel_host`, `recv_cand`, `compact`).  Afterwards `compact` is the pass's phase-A
+    result for ALL slides in loader order: X = world pieces of `mx` rows, cand transposed to [2C+2, rows], n_sel and
+    row_off per slide.  Device-agnostic (the CPU tests run it over gloo); `sync(tensor)` makes a device->host copy
+    that is safe to read (default: the copy is synchronous).  -> (mx, rows this rank sent)."""
+    cb = st["compact"]
+    if world > 1:
+        _all_gather_into(st["all_nsel"], st["send_nsel"], group)
+    else:
+        st["all_nsel"].copy_(st["send_nsel"])
+    if sync is None:
+        st["nsel_host"].copy_(st["all_nsel"])
+    else:
+        sync(st["nsel_host"], st["all_nsel"])
+    counts = st["nsel_host"].tolist()
+    mx, row_off, n_sel = seq_layout([counts[r * per:r * per + n_by_rank[r]] for r in range(world)])
+    assert world * mx <= cb.total
+    if world > 1:
+        _all_gather_into(cb.X[:world * mx], st["send_feat"][:mx], group)
+        _all_gather_into(st["recv_cand"][:world * mx], st["send_cand"][:mx], group)
+        cand_rows = st["recv_cand"][:world * mx]
+    else:
+        cand_rows = st["send_cand"][:mx]                   # (cb.X is the send buffer itself)
+    cb.cand[:, :world * mx].copy_(cand_rows.t())
+    return mx, row_off, n_sel
+
+
 def _seq_issue(sh, plan, turn, bank, rng_before, group, host_wait=None):
     """Masks of the whole pass from generator state `rng_before` (every rank draws the same stream and keeps its own
-    rows), phase A of this rank's slides, their compact result into the send buffers, three all-gathers: afterwards
-    set `turn`'s CompactBatch holds the pass's phase-A result for ALL slides, in loader order.  On the CURRENT stream.
+    rows), phase A of this rank's slides, their selections packed back to back, then the hand-over (seq_exchange: one
+    small all-gather of the counts, two of the unpadded pieces): afterwards set `turn`'s CompactBatch holds the pass's
+    phase-A result for ALL slides, in loader order.  On the CURRENT stream; the host waits once, for the counts.
     -> generator state after the draws (None: torch drew for us)."""
     from . import engine
     st = plan["sets"][turn]
@@ -652,18 +781,20 @@ def _seq_issue(sh, plan, turn, bank, rng_before, group, host_wait=None):
         b = st["local"]
         b.use_host_mask(mine, int(mine.sum()))
         b.phase_a(bank)
-        engine.pack_selected(b, 0, n_loc, cap, st["send_feat"], st["send_cand"])
+        engine.pack_selected_rows(b, 0, n_loc, cap, st["send_feat"], st["send_cand"])
         st["send_nsel"][:n_loc].copy_(b.n_sel)
+
+    def sync(host, devt):
+        host.copy_(devt, non_blocking=True)
+        e = torch.cuda.Event()
+        e.record()
+        e.synchronize()
+    mx, row_off, _ = seq_exchange(st, plan["n_by_rank"], sh.per, sh.world, group, sync)
     cb = st["compact"]
-    if sh.world > 1:
-        _all_gather_into(cb.X, st["send_feat"], group)
-        _all_gather_into(cb.cand_blocks, st["send_cand"], group)
-        _all_gather_into(cb.n_sel, st["send_nsel"], group)
-    else:
-        cb.X.copy_(st["send_feat"])
-        cb.cand_blocks.copy_(st["send_cand"])
-        cb.n_sel.copy_(st["send_nsel"])
-    cb.blocks_to_columns()
+    cb.n_sel.copy_(st["all_nsel"][plan["order"]])       # loader order
+    cb.set_layout(row_off)
+    plan["sent_rows"] += mx
+    plan["padded_rows"] += sh.per * cap
     ev = torch.cuda.Event()
     ev.record()
     if buf is not None:
@@ -704,9 +835,8 @@ def train_seq(model, shard: SeqShardedBags, optimizer, device, args, group=None)
             shard.repeat_num, shard.next_pass_len = keep_rep, keep_next
         return
     use = engine.train_use_bits(args.discard_classifiers)
-    X_like = shard.local.X if shard.local is not None else None
-    assert X_like is not None, "train_seq: every rank must hold at least one slide"
-    bank = M._bank_for(X_like, device)
+    assert shard.local is not None                     # (SeqShardedBags refuses world > slides, on every rank alike)
+    bank = M._bank_for(shard.local.X, device)
     assert bank.C == args.n_classes
     m = len(shard)
     plan = _seq_plan(shard, m, bank, args)

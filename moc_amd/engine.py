@@ -149,6 +149,7 @@ class SlideBatch:
         self.mask.copy_(host_mask_u8, non_blocking=True)
         self.c.mask = ptr(self.mask)
         self.kept_rows_host = int(kept_rows)
+        self.c.max_rows = max(self.sizes)       # (use_host_mask may have tightened it to ANOTHER mask's kept rows)
 
     def use_host_mask(self, pinned_mask_u8: torch.Tensor, kept_rows: int, max_kept: int | None = None):
         """Keep flags read by the compaction kernel straight from PINNED host memory (device-mapped by
@@ -210,25 +211,29 @@ class SlideBatch:
 
 
 class CompactBatch(SlideBatch):
-    """Phase A's RESULT for n slides, `cap` slots each, with no bag behind it: the selected rows themselves
-    (`Xc` [n*cap, D]), their candidate scores (`cand` [2C+2, n*cap]) and `n_sel` [n] -- what moc_pack_selected
-    writes and the exact-sequential multi-GPU mode all-gathers (dist.train_seq).  The phase-B entry points take it
-    like any batch: slot b*cap+i is row b*cap+i of Xc (sel_row is the identity)."""
+    """Phase A's RESULT for n slides with no bag behind it: the selected rows themselves (`X` [rows, D]), their
+    candidate scores (`cand` [2C+2, rows]) and `n_sel` [n] -- what moc_pack_selected_rows writes on every rank and
+    the exact-sequential multi-GPU mode all-gathers (dist.train_seq).  The phase-B entry points take it like any
+    batch: sel_row is the identity, slide b's rows are X[row_off[b] : row_off[b] + n_sel[b]] -- and row_off is set
+    per pass (set_layout): the gathered pieces are as long as the pass's selections make them."""
 
-    def __init__(self, n_slides: int, cap: int, D: int, dtype: torch.dtype, C_: int, Ce: int, topj: int, topk: int, device):
-        T = n_slides * cap
+    def __init__(self, n_slides: int, rows: int, cap: int, D: int, dtype: torch.dtype, C_: int, Ce: int, topj: int, topk: int,
+                 device, X: torch.Tensor | None = None):
+        T = int(rows)
         self.device, self.n_slides, self.total, self.D = device, int(n_slides), T, int(D)
         self.C, self.Ce, self.topj, self.topk, self.cap = int(C_), int(Ce), int(topj), int(topk), int(cap)
         self.sizes = [cap] * n_slides
-        self.X = torch.zeros((T, D), dtype=dtype, device=device)
-        self.cand_blocks = torch.zeros((n_slides, 2 * self.C + 2, cap), dtype=torch.float32, device=device)
+        self.X = X if X is not None else torch.zeros((T, D), dtype=dtype, device=device)
+        assert tuple(self.X.shape) == (T, D) and self.X.dtype == dtype
         self.cand = torch.zeros((2 * self.C + 2, T), dtype=torch.float32, device=device)
         self.n_sel = torch.zeros(n_slides, dtype=torch.int32, device=device)
         self.sel_row = torch.arange(T, dtype=torch.int64, device=device)
-        off = [b * cap for b in range(n_slides + 1)]
-        self.row_off_host = off
-        self._row_off_c = (C.c_int64 * len(off))(*off)
-        self.row_off = torch.tensor(off, dtype=torch.int64).to(device)
+        self.row_off_host = [0] * (n_slides + 1)
+        self._row_off_c = (C.c_int64 * (n_slides + 1))()
+        self._row_off_pin = torch.zeros(n_slides + 1, dtype=torch.int64)
+        if torch.device(device).type == "cuda":
+            self._row_off_pin = self._row_off_pin.pin_memory()
+        self.row_off = torch.zeros(n_slides + 1, dtype=torch.int64, device=device)
         self.discard_bits, self.mask, self.kept_rows_host = 0, None, T
         self.c = MocBatch(
             X=ptr(self.X), dtype=_dtype_code(dtype), D=self.D, total_rows=T, n_slides=self.n_slides, max_rows=cap,
@@ -237,9 +242,16 @@ class CompactBatch(SlideBatch):
             stats=None, sel_flag=None, sel_idx=None, sel_row=ptr(self.sel_row), n_sel=ptr(self.n_sel), cand=ptr(self.cand))
         self._ws = None
 
-    def blocks_to_columns(self):
-        """cand_blocks [n][2C+2][cap] (as gathered) -> cand [2C+2][n*cap] (as phase B reads it)."""
-        self.cand.view(2 * self.C + 2, self.n_slides, self.cap).copy_(self.cand_blocks.permute(1, 0, 2))
+    def set_layout(self, row_off):
+        """First row of every slide (+ the end) for the pass whose pieces were just gathered: host copy for the kernel
+        arguments of the single-slide launches, device copy (stream-ordered, from a pinned buffer the caller does not
+        touch again before this set's steps have run) for the kernels that read row_off themselves."""
+        assert len(row_off) == self.n_slides + 1 and row_off[-1] <= self.total
+        self.row_off_host = [int(v) for v in row_off]
+        for i, v in enumerate(self.row_off_host):
+            self._row_off_c[i] = v
+        self._row_off_pin.copy_(torch.tensor(self.row_off_host, dtype=torch.int64))
+        self.row_off.copy_(self._row_off_pin, non_blocking=True)
 
 
 def pack_selected(batch: SlideBatch, slide0: int, n: int, cap: int, feat_out: torch.Tensor, cand_out: torch.Tensor):
@@ -247,6 +259,16 @@ def pack_selected(batch: SlideBatch, slide0: int, n: int, cap: int, feat_out: to
     assert feat_out.is_contiguous() and cand_out.is_contiguous() and feat_out.dtype == batch.X.dtype
     assert feat_out.numel() >= n * cap * batch.D and cand_out.numel() >= n * (2 * batch.C + 2) * cap
     check(lib().moc_pack_selected(C.byref(batch.c), slide0, n, cap, ptr(feat_out), ptr(cand_out), _stream()), "moc_pack_selected")
+
+
+def pack_selected_rows(batch: SlideBatch, slide0: int, n: int, cap: int, feat_out: torch.Tensor, cand_out: torch.Tensor):
+    """moc_pack_selected_rows: slides [slide0, slide0+n) of `batch` (phase A done), unpadded -> feat_out [rows, D] (slide
+    b's rows behind those of the slides before it), cand_out [rows, 2C+2] row-major."""
+    assert feat_out.is_contiguous() and cand_out.is_contiguous() and feat_out.dtype == batch.X.dtype
+    rows = feat_out.size(0)
+    assert feat_out.size(1) == batch.D and tuple(cand_out.shape) == (rows, 2 * batch.C + 2)
+    check(lib().moc_pack_selected_rows(C.byref(batch.c), slide0, n, cap, ptr(feat_out), ptr(cand_out), rows, _stream()),
+          "moc_pack_selected_rows")
 
 
 class MetaState:

@@ -58,18 +58,31 @@ def command(a, shot, fold):
 
 
 def visible_gpus():
+    """What a child's HIP_VISIBLE_DEVICES must say for each device THIS process sees, in order.  With a HIP / CUDA mask
+    in the parent's environment (a scheduler's allocation) those are the mask's own entries -- bare indices 0..n-1 would
+    point at the node's first GPUs, outside the allocation; ROCR_VISIBLE_DEVICES is left in place, HIP indices being
+    relative to it."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip():
+            return [e.strip() for e in v.split(",") if e.strip()]
     import torch
-    return list(range(torch.cuda.device_count()))           # (counting devices does not initialise the GPU)
+    return [str(i) for i in range(torch.cuda.device_count())]          # (counting devices does not initialise the GPU)
 
 
 def main(argv=None):
     a = parse(argv)
-    gpus = a.gpus if a.gpus is not None else visible_gpus()
+    seen = visible_gpus()
+    if a.gpus is not None:                                   # --gpus: positions among the devices this process sees
+        assert all(0 <= g < len(seen) for g in a.gpus) or not seen, f"--gpus {a.gpus}: this process sees {len(seen)} device(s)"
+        gpus = [seen[g] if seen else str(g) for g in a.gpus]
+    else:
+        gpus = seen
     assert gpus and a.runs_per_gpu >= 1, "no GPU to run on"
     queue = jobs_of(a)
     slots = {(g, k): None for g in gpus for k in range(a.runs_per_gpu)}       # slot -> (Popen, shot, fold, log, t0)
     if a.dry_run:
-        order = sorted(slots)
+        order = sorted(slots, key=lambda k: (k[1], k[0]))      # as below: every GPU's first slot before any second one
         for i, (shot, fold) in enumerate(queue):
             cmd, _, log = command(a, shot, fold)
             print(f"gpu {order[i % len(order)][0]}: {' '.join(cmd)} >> {log}")
@@ -83,7 +96,6 @@ def main(argv=None):
                 cmd, out_dir, log = command(a, shot, fold)
                 os.makedirs(out_dir, exist_ok=True)
                 env = dict(os.environ, HIP_VISIBLE_DEVICES=str(key[0]), CUDA_VISIBLE_DEVICES=str(key[0]))
-                env.pop("ROCR_VISIBLE_DEVICES", None)
                 pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))     # `-m moc_amd.run_moc` from any cwd
                 env["PYTHONPATH"] = pkg_parent + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
                 fh = open(log, "a")

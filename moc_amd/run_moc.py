@@ -296,7 +296,17 @@ def cli(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:                                   # one process per GPU under a launcher (torch.distributed.run)
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # everything that can be refused from the command line alone is refused HERE, on every rank alike, before the
+        # process group exists: a rank that leaves later would strand its peers inside a collective
+        if args.seed is None:
+            raise SystemExit("multi-GPU runs need --seed: every rank must build the same meta-learner and draw the same masks")
+        if args.loader_seed_draw:
+            raise SystemExit("--loader_seed_draw is a one-GPU option: the sharded splits do not make the DataLoader's per-pass "
+                             "base-seed draw, so the mask stream would differ from the same command on one GPU")
+        if args.synthetic and world > args.shot * (2 if args.dataset == "nsclc" else 3 if args.dataset == "rcc" else 12 if args.dataset == "ebrains12" else 30):
+            raise SystemExit(f"the train split has fewer slides than the job has ranks ({world}): every rank must hold at least one")
+        # (RCCL sets up its own IPC; this script maps no peer memory by hand and leaves HSA_ENABLE_IPC_MODE_LEGACY as the
+        # launcher's environment has it)
         device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         torch.cuda.set_device(device)
         dist.init_process_group("nccl", device_id=device)
@@ -305,8 +315,6 @@ def cli(argv=None):
     train_loader, val_loader, test_loader = prepare(args, device)
     if args.seed is not None:
         torch.manual_seed(args.seed)
-    elif world > 1:
-        raise SystemExit("multi-GPU runs need --seed: every rank must build the same meta-learner and draw the same masks")
     model = M.senet(512, 4).to(device)                                                   # main_moc.py:315
     optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)         # main_moc.py:316
     try:

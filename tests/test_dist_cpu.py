@@ -150,11 +150,16 @@ def test_sharded_eval_gather_world2():
 
 # ------------------------------------------------------------------ splits spread over the ranks (round 2)
 def test_block_lists_are_contiguous_and_partition():
-    for n, w in [(7, 3), (32, 8), (5, 8), (48, 4), (1, 2)]:
+    for n, w in [(7, 3), (32, 8), (5, 8), (48, 4), (1, 2), (12, 8), (2, 2), (4, 3)]:
         blocks = mdist.block_lists(n, w)
         assert len(blocks) == w and sum(blocks, []) == list(range(n))
         per = (n + w - 1) // w
         assert all(len(b) <= per for b in blocks)
+        # balanced: sizes differ by at most one, the longer blocks first -- so no rank is empty unless w > n
+        lens = [len(b) for b in blocks]
+        assert max(lens) - min(lens) <= 1 and lens == sorted(lens, reverse=True)
+        assert (min(lens) >= 1) == (w <= n)
+    assert [len(b) for b in mdist.block_lists(12, 8)] == [2, 2, 2, 2, 1, 1, 1, 1]      # (ceil-sized blocks: 2 x 6, then two empty ranks)
     with pytest.raises(AssertionError, match="partition"):
         mdist.ShardedSplit([], [], [0, 1, 0], [[0, 1], [1, 2]], "cpu")
 
@@ -198,3 +203,90 @@ def test_to_sharded_reads_blocks_and_agrees_on_the_layout(tmp_path):
     assert (out[0]["lo"], out[0]["hi"], out[1]["lo"], out[1]["hi"]) == (0, 4, 4, 7)
     assert out[0]["local_sizes"] == sizes[:4] and out[1]["local_sizes"] == sizes[4:]
     assert out[0]["val_local"] == [10, 11] and out[1]["val_local"] == [12]
+
+
+# ------------------------------------------------------------------ exact-sequential hand-over (round 3): layout + unpadded gather
+def test_more_ranks_than_train_slides_is_refused_on_every_rank_before_any_collective():
+    """world 3, two train slides (NSCLC 1-shot has 2): decided from (n, world) alone, so every rank raises the same
+    ValueError in the constructor -- no process group exists here at all, so nothing collective can have been entered."""
+    for rank in range(3):
+        with pytest.raises(ValueError, match="has 2 slide.*3 ranks"):
+            mdist.SeqShardedBags([], [900, 1100], [0, 1], "cpu", rank, 3)
+
+
+def test_seq_layout_packs_every_rank_to_the_largest_sum():
+    mx, row_off, n_sel = mdist.seq_layout([[5, 7], [4], [9, 1]])
+    assert mx == 12 and n_sel == [5, 7, 4, 9, 1]
+    assert row_off == [0, 5, 12, 24, 33, 34]                  # rank r's piece starts at r * mx, its slides back to back
+    mx, row_off, n_sel = mdist.seq_layout([[3], [], [2, 2]])  # a rank with no slide in this (partial) pass
+    assert mx == 4 and row_off == [0, 8, 10, 12] and n_sel == [3, 2, 2]
+    with pytest.raises(AssertionError, match="selected no row"):
+        mdist.seq_layout([[3, 0]])
+
+
+def _count(g):
+    return 3 + (7 * g) % 11
+
+
+def _seq_exchange_worker(rank, world, n, m, cap, D, C):
+    """What _seq_issue does after phase A, on CPU tensors over gloo: every rank 'selected' _count(g) rows of slide g,
+    row t of slide g holding the value 1000 g + t; after the hand-over EVERY rank must hold every slide's rows, in loader
+    order, at the offsets of seq_layout -- having sent only its own unpadded piece."""
+    from moc_amd.engine import CompactBatch
+    blocks = mdist.block_lists(n, world)
+    per = max(len(b) for b in blocks)
+    n_by_rank = [max(0, min(m, b[-1] + 1) - b[0]) for b in blocks]
+    nk = 2 * C + 2
+    st = {"send_feat": torch.zeros(per * cap, D), "send_cand": torch.zeros(per * cap, nk), "send_nsel": torch.zeros(per, dtype=torch.int32),
+          "all_nsel": torch.zeros(world * per, dtype=torch.int32), "nsel_host": torch.zeros(world * per, dtype=torch.int32),
+          "recv_cand": torch.zeros(world * per * cap, nk)}
+    recv = st["send_feat"] if world == 1 else torch.zeros(world * per * cap, D)
+    st["compact"] = CompactBatch(m, world * per * cap, cap, D, torch.float32, C, C + 4, 400, 10, "cpu", X=recv)
+    o = 0
+    for i in range(n_by_rank[rank]):
+        g = blocks[rank][i]
+        c = _count(g)
+        st["send_nsel"][i] = c
+        vals = 1000.0 * g + torch.arange(c, dtype=torch.float32)
+        st["send_feat"][o:o + c] = vals[:, None]
+        st["send_cand"][o:o + c] = vals[:, None] + 0.001 * torch.arange(nk)[None, :]
+        o += c
+    mx, row_off, n_sel = mdist.seq_exchange(st, n_by_rank, per, world)
+    cb = st["compact"]
+    assert n_sel == [_count(g) for g in range(m)]
+    assert mx == max(sum(_count(g) for g in blocks[r][:n_by_rank[r]]) for r in range(world)) and o <= mx
+    for g in range(m):
+        rows = cb.X[row_off[g]:row_off[g] + n_sel[g]]
+        exp = 1000.0 * g + torch.arange(n_sel[g], dtype=torch.float32)
+        assert torch.equal(rows, exp[:, None].expand(-1, D)), f"slide {g}: rows"
+        for k in range(nk):
+            assert torch.allclose(cb.cand[k, row_off[g]:row_off[g] + n_sel[g]], exp + 0.001 * k), f"slide {g}: candidate column {k}"
+    cb.set_layout(row_off)
+    assert cb.row_off.tolist() == row_off and [cb._row_off_c[i] for i in range(m + 1)] == row_off
+    return dict(mx=mx, sent=o, padded=per * cap, row_off=row_off)
+
+
+@pytest.mark.parametrize("world,n,m", [(4, 11, 11), (4, 11, 9), (8, 12, 12), (8, 32, 32), (8, 9, 3), (2, 2, 2)])
+def test_seq_exchange_gathers_unpadded_pieces_in_loader_order(world, n, m):
+    """gloo, world 4 and 8, uneven splits (n % world != 0), partial passes that leave trailing ranks nothing to send."""
+    out = _run(_seq_exchange_worker, world, n, m, 16, 8, 2)
+    assert len({tuple(out[r]["row_off"]) for r in range(world)}) == 1, "ranks disagree on the layout"
+    assert all(out[r]["mx"] == out[0]["mx"] and out[r]["sent"] <= out[r]["mx"] < out[r]["padded"] for r in range(world))
+
+
+def _direct_rccl_worker(rank, world):
+    """Rank 1 cannot load librccl: BOTH ranks must come out with ok == False (and neither may hang in a collective
+    the other skipped).  gloo: the agreement words travel through torch.distributed."""
+    if rank == 1:
+        os.environ["MOC_RCCL_LIB"] = "/nonexistent/librccl.so"
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        d = mdist.DirectRccl("cpu")
+    return (d.ok, [str(x.message) for x in w])
+
+
+def test_direct_rccl_setup_failure_on_one_rank_is_agreed_by_all():
+    out = _run(_direct_rccl_worker, 2)
+    assert out[0][0] is False and out[1][0] is False
+    assert any("direct RCCL unavailable" in m for m in out[0][1]) and any("librccl" in m for m in out[1][1])

@@ -59,9 +59,8 @@ def _seq_run(dev, rank, world, C, j, K, store, group=None, hints=True):
     torch.manual_seed(5)
     model = M.senet(512, 4).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
-    per = (len(SIZES) + world - 1) // world
-    lo, hi = min(len(SIZES), rank * per), min(len(SIZES), (rank + 1) * per)
-    sh = mdist.SeqShardedBags(bags[lo:hi], SIZES, labels, dev, rank, world, dtype=store)
+    blk = mdist.block_lists(len(SIZES), world)[rank]
+    sh = mdist.SeqShardedBags([bags[i] for i in blk], SIZES, labels, dev, rank, world, dtype=store)
     torch.manual_seed(100)
     losses = []
     for i, rn in enumerate(PASSES):
@@ -104,8 +103,9 @@ def _worker(rank, world, port, q, C, j, K):
         q.put((rank, "ERR " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,C,j,K", [(2, 2, 100, 10), (3, 2, 100, 10), (2, 30, 40, 5)])
+@pytest.mark.parametrize("world,C,j,K", [(2, 2, 100, 10), (3, 2, 100, 10), (2, 30, 40, 5), (5, 2, 100, 10)])
 def test_ranks_sharing_one_device_are_bit_identical_to_one_gpu(gpu_device, world, C, j, K):
+    """(world 5 over 7 slides: blocks of 2, 2, 1, 1, 1 -- and the 5-slide partial pass leaves ranks 3 and 4 nothing)"""
     ctx = mp.get_context("spawn")
     q, port = ctx.Queue(), _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, C, j, K)) for r in range(world)]

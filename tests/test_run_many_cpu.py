@@ -16,6 +16,7 @@ t0 = time.time()
 time.sleep(0.5)
 print("hello from", fold, shot)
 rec = dict(fold=int(fold), shot=int(shot), gpu=os.environ["HIP_VISIBLE_DEVICES"], cuda=os.environ["CUDA_VISIBLE_DEVICES"],
+           rocr=os.environ.get("ROCR_VISIBLE_DEVICES"),
            t0=t0, t1=time.time(), rest=a, out=out)
 open(os.path.join(os.environ["FAKE_LOG_DIR"], f"{shot}_{fold}.json"), "w").write(json.dumps(rec))
 sys.exit(3 if (fold, shot) == ("1", "2") and os.environ.get("FAKE_FAIL") else 0)
@@ -64,3 +65,15 @@ def test_dry_run_prints_the_commands(tmp_path, capsys):
     rc = run_many.main(["--folds", "0", "1", "--shots", "16", "--gpus", "3", "--dry-run", "--result_dir", str(tmp_path), "--", "--dataset", "rcc"])
     out = capsys.readouterr().out
     assert rc == 0 and out.count("moc_amd.run_moc") == 2 and "--shot 16" in out and "--dataset rcc" in out and "gpu 3:" in out
+
+
+def test_children_stay_inside_the_parents_device_mask(tmp_path, monkeypatch, capsys):
+    """A scheduler hands this process GPUs 4 and 5 (HIP_VISIBLE_DEVICES=4,5, possibly under a ROCR mask): the children
+    must be pinned to 4 and 5 -- not to indices 0 and 1 of the node -- and the ROCR mask must survive."""
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,1,2,3,4,5")
+    rc = run_many.main(["--folds", "0", "1", "--shots", "16", "--dry-run", "--result_dir", str(tmp_path), "--", "--dataset", "rcc"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "gpu 4:" in out and "gpu 5:" in out and "gpu 0:" not in out
+    rc, recs = _run(tmp_path, monkeypatch)                    # --gpus 0 1: positions in the mask
+    assert rc == 0 and {r["gpu"] for r in recs} == {"4", "5"} and all(r["rocr"] == "0,1,2,3,4,5" for r in recs)
