@@ -46,6 +46,22 @@ enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
 /* storage type of the bag X; arithmetic is always fp32-accumulate */
 enum { MOC_F32 = 0, MOC_BF16 = 1, MOC_F16 = 2 };
 
+/* moc_batch_t.flags.  MOC_STATS_COMPACT: the score pass writes C+5 statistics per row instead of 2C+3 -- the C softmax
+ * columns (patch_selection_classifier_index.py:34) are not stored; their consumers (moc_select's psi_sigma keys,
+ * moc_gather_candidates' s_sigma) re-form softmax[c] = exp2((logit[c] - m1) * log2 e) * (1/den) from the row maximum m1
+ * and the reciprocal of the denominator, with the score pass's own arithmetic: the same bits.  For wide banks, where the
+ * statistics are a quarter of the pass's HBM traffic (thirty classes: 253 -> 141 bytes per 1 KiB row).  moc_row_stats
+ * and callers that read `stats` themselves (the zero-shot poolings) use the full layout. */
+enum { MOC_STATS_COMPACT = 1,
+       /* moc_select: one workgroup per column even for wide banks (the default there is one workgroup per slide and
+        * group of eight columns); both give the same flags -- this bit exists so that tests can say so */
+       MOC_SELECT_PER_COLUMN = 2,
+       /* evaluation passes: moc_gather_candidates does not materialise the [2C+2, S] candidate columns of wide banks
+        * (C > 4) and moc_meta_forward reads a selected row's four scores (main_moc.py:359-366, :482-492) straight from
+        * `stats` through sel_idx -- the same values.  Entry points that need `cand` itself (the train steps,
+        * moc_mix_fixed, moc_pack_selected*) refuse such a batch. */
+       MOC_CAND_FROM_STATS = 4 };
+
 /* bits of `discard_bits`, in the order of main_moc.py:341-350 */
 enum { MOC_SEL_TOPK = 1, MOC_SEL_DELTA_SOFTMAX = 2, MOC_SEL_DELTA_DIFF = 4, MOC_SEL_BOTTOMK = 8 };
 
@@ -80,13 +96,15 @@ typedef struct moc_batch {
     int32_t        topj;       /* --topj                                                 */
     int32_t        topk;       /* --topk                                                 */
     uint32_t       discard_bits;
-    uint32_t       reserved;
+    uint32_t       flags;      /* MOC_STATS_COMPACT or 0 (the field was `reserved`, always 0, before round 3) */
     /* ---- work arrays (device) ---- */
     int32_t* kept;       /* [total_rows + 16] slot -> row index inside its slide (unused if mask==NULL);
                             the 16 entries of slack let the score pass read a tile's 16 indices
                             with one scalar load without running off the allocation            */
     int32_t* n_kept;     /* [n_slides]                                                               */
-    float*   stats;      /* [2C+3, total_rows] per-slot: logits[C] | softmax[C] | gap | bg_sum | bg_max  */
+    float*   stats;      /* [2C+3, total_rows] per-slot: logits[C] | softmax[C] | gap | bg_sum | bg_max;
+                            with MOC_STATS_COMPACT only the first C+5 rows are used:
+                            logits[C] | m1 | 1/den | gap | bg_sum | bg_max                                 */
     uint8_t* sel_flag;   /* [total_rows]      union membership                                        */
     int32_t* sel_idx;    /* [total_rows]      selected_index of slide b at [row_off[b], +n_sel[b])     */
     int64_t* sel_row;    /* [total_rows]      same positions: row of X (packed) to gather             */

@@ -18,6 +18,9 @@ LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
 ABI_VERSION = 14
 
 MOC_F32, MOC_BF16, MOC_F16 = 0, 1, 2
+MOC_STATS_COMPACT = 1
+MOC_SELECT_PER_COLUMN = 2
+MOC_CAND_FROM_STATS = 4
 SEL_BITS = {"topk": 1, "delta_softmax": 2, "delta_diff": 4, "bottomk": 8}
 
 _p = C.c_void_p
@@ -28,7 +31,7 @@ class MocBatch(C.Structure):
         ("X", _p), ("dtype", C.c_int32), ("D", C.c_int32), ("total_rows", C.c_int64),
         ("n_slides", C.c_int32), ("max_rows", C.c_int32), ("row_off", _p), ("row_off_host", _p), ("x_off", _p), ("mask", _p),
         ("C", C.c_int32), ("Ce", C.c_int32), ("topj", C.c_int32), ("topk", C.c_int32),
-        ("discard_bits", C.c_uint32), ("reserved", C.c_uint32),
+        ("discard_bits", C.c_uint32), ("flags", C.c_uint32),
         ("kept", _p), ("n_kept", _p), ("stats", _p), ("sel_flag", _p), ("sel_idx", _p),
         ("sel_row", _p), ("n_sel", _p), ("cand", _p),
     ]

@@ -40,6 +40,13 @@ __device__ __forceinline__ uint32_t moc_key_desc(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// softmax[c] of a row as the score pass forms it (row_stats_emit: e * rden with e = exp2((v - m1) log2 e)): the same
+// instructions, hence the same bits -- the compact statistics (MOC_STATS_COMPACT) store (v, m1, 1/den) instead of the C
+// softmax columns, and every consumer re-forms the value with this function
+__device__ __forceinline__ float moc_softmax_from(float v, float m1, float rden) {
+    return __builtin_amdgcn_exp2f((v - m1) * 1.44269504088896340736f) * rden;
+}
+
 __device__ __forceinline__ float moc_bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 // round-to-nearest-even fp32 -> bf16 bits (finite inputs)

@@ -66,7 +66,38 @@ struct FwdArgs {
     int64_t base_host;              // >= 0: first slot of the (single) slide, known to the host
     int D, C, slide0;
     uint32_t use_bits;
+    // where the four candidate scores of a selected row come from (main_moc.py:359-366).  0: the materialised `cand`
+    // columns (moc_gather_candidates).  1 / 2: straight from the score pass's statistics (full / compact layout) through
+    // sel_idx -- MOC_CAND_FROM_STATS: evaluation passes, which then never write or read the [2C+2, S] candidate array
+    // (at thirty classes 545 MB written and read back per 202 slides).  Same values, same bits.
+    int cand_mode;
+    const float* stats;
+    const int32_t* sel_idx;
 };
+
+// the row of a selected slot o in whichever array holds its candidate scores: column k of it is ptr[k * stride]
+__device__ __forceinline__ const float* cand_row(const FwdArgs& a, int64_t base, int o) {
+    if (a.cand_mode == 0) return a.cand + base + o;
+    return a.stats + base + a.sel_idx[base + o];
+}
+// the two per-row scores s_delta = |top1 - top2| and s_beta = max background logit
+__device__ __forceinline__ void cand_row_scores(const FwdArgs& a, const float* cd, float& s2, float& s3) {
+    const int C = a.C;
+    if (a.cand_mode == 2) { s2 = cd[(int64_t)(C + 2) * a.stride]; s3 = cd[(int64_t)(C + 4) * a.stride]; }
+    else if (a.cand_mode == 1) { s2 = cd[(int64_t)(2 * C) * a.stride]; s3 = cd[(int64_t)(2 * C + 2) * a.stride]; }
+    else { s2 = cd[(int64_t)(2 * C) * a.stride]; s3 = cd[(int64_t)(2 * C + 1) * a.stride]; }
+}
+// (m1, 1/den) of the row: only the compact statistics need them (s_sigma is re-formed)
+__device__ __forceinline__ void cand_row_norm(const FwdArgs& a, const float* cd, float& m1, float& rden) {
+    m1 = 0.f; rden = 0.f;
+    if (a.cand_mode == 2) { m1 = cd[(int64_t)a.C * a.stride]; rden = cd[(int64_t)(a.C + 1) * a.stride]; }
+}
+// s_p and s_sigma of class c
+__device__ __forceinline__ void cand_class_scores(const FwdArgs& a, const float* cd, int c, float m1, float rden, float& s0, float& s1) {
+    s0 = cd[(int64_t)c * a.stride];
+    if (a.cand_mode == 2) s1 = moc_softmax_from(s0, m1, rden);
+    else s1 = cd[(int64_t)(a.C + c) * a.stride];
+}
 
 // ---- W1 image ----------------------------------------------------------------------------
 // The forward's B operand is W1^T: B[k][n] = W1[n][k].  Read from the [H][D] parameter tensor,
@@ -128,11 +159,11 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
     float pre_c[4] = {0.f, 0.f, 0.f, 0.f};
     if (threadIdx.x < 16 * C && row0 + (threadIdx.x & 15) < S) {
         const int r = threadIdx.x & 15, c = threadIdx.x >> 4;
-        const float* cd = a.cand + base + row0 + r;
-        pre_c[0] = cd[(int64_t)c * a.stride];
-        pre_c[1] = cd[(int64_t)(C + c) * a.stride];
-        pre_c[2] = cd[(int64_t)(2 * C) * a.stride];
-        pre_c[3] = cd[(int64_t)(2 * C + 1) * a.stride];
+        const float* cd = cand_row(a, base, row0 + r);
+        float m1, rden;
+        cand_row_norm(a, cd, m1, rden);
+        cand_class_scores(a, cd, c, m1, rden, pre_c[0], pre_c[1]);
+        cand_row_scores(a, cd, pre_c[2], pre_c[3]);
     }
     const float w2_pre = a.W2[threadIdx.x & 255];
     const float bias = a.b1[wave * 16 + (lane & 15)];
@@ -240,9 +271,11 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
         if (row0 + r >= S) continue;
         float s0 = pre_c[0], s1 = pre_c[1], s2 = pre_c[2], s3 = pre_c[3];
         if (e >= 256) {   // C > 16: beyond the prefetched element
-            const float* cd = a.cand + base + row0 + r;
-            s0 = cd[(int64_t)c * a.stride]; s1 = cd[(int64_t)(C + c) * a.stride];
-            s2 = cd[(int64_t)(2 * C) * a.stride]; s3 = cd[(int64_t)(2 * C + 1) * a.stride];
+            const float* cd = cand_row(a, base, row0 + r);
+            float m1, rden;
+            cand_row_norm(a, cd, m1, rden);
+            cand_class_scores(a, cd, c, m1, rden, s0, s1);
+            cand_row_scores(a, cd, s2, s3);
         }
         float v = 0.f;   // 0 + x == x exactly, so this is the reference's running sum in both modes
         if (a.use_bits & 1u) v = __fadd_rn(v, __fmul_rn(Gs[r][0], s0));
@@ -277,20 +310,17 @@ __global__ __launch_bounds__(256) void meta_forward64_kernel(FwdArgs a) {
     // 32 classes here (later chunks of 32 are requested a chunk at a time, all loads before the first store).
     const int er = threadIdx.x & 63, ec0 = threadIdx.x >> 6;
     const bool erow_ok = row0 + er < S;
-    const float* ecd = a.cand + base + row0 + er;
-    float es2 = 0.f, es3 = 0.f, es0[8], es1[8];
+    const float* ecd = cand_row(a, base, erow_ok ? row0 + er : row0);
+    float es2 = 0.f, es3 = 0.f, em1 = 0.f, erd = 0.f, es0[8], es1[8];
     if (erow_ok) {
-        es2 = ecd[(int64_t)(2 * C) * a.stride];
-        es3 = ecd[(int64_t)(2 * C + 1) * a.stride];
+        cand_row_scores(a, ecd, es2, es3);
+        cand_row_norm(a, ecd, em1, erd);
     }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int c = ec0 + 4 * it;
         es0[it] = es1[it] = 0.f;
-        if (erow_ok && c < C) {
-            es0[it] = ecd[(int64_t)c * a.stride];
-            es1[it] = ecd[(int64_t)(C + c) * a.stride];
-        }
+        if (erow_ok && c < C) cand_class_scores(a, ecd, c, em1, erd, es0[it], es1[it]);
     }
     const float w2_pre = a.W2[threadIdx.x & 255];
     const float bias = a.b1[wave * 16 + (lane & 15)];
@@ -366,10 +396,7 @@ __global__ __launch_bounds__(256) void meta_forward64_kernel(FwdArgs a) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int c = cb + ec0 + 4 * it;
-                if (erow_ok && c < C) {
-                    es0[it] = ecd[(int64_t)c * a.stride];
-                    es1[it] = ecd[(int64_t)(C + c) * a.stride];
-                }
+                if (erow_ok && c < C) cand_class_scores(a, ecd, c, em1, erd, es0[it], es1[it]);
             }
         }
 #pragma unroll
@@ -1522,6 +1549,8 @@ int check_meta(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* w
     MOC_REQUIRE((!need_h1 || (ws->H1 && ws->gates)) && ws->mixed && ws->pooled && ws->topk_idx && ws->topk_cnt && ws->loss && ws->pred,
                 "%s: null work array", who);
     MOC_REQUIRE(B->sel_row && B->n_sel && B->cand, "%s: batch has no phase-A outputs", who);
+    MOC_REQUIRE(!(B->flags & MOC_CAND_FROM_STATS) || !(need_adam || need_grad),
+                "%s: a MOC_CAND_FROM_STATS batch has no materialised candidate scores (evaluation only)", who);
     MOC_REQUIRE(B->topk <= 256 && B->C <= 256, "%s: topk/C too large for the fused step (<= 256)", who);
     if (need_adam)
         MOC_REQUIRE(M->m_W1 && M->m_b1 && M->m_W2 && M->m_b2 && M->v_W1 && M->v_b1 && M->v_W2 && M->v_b2,
@@ -1553,6 +1582,12 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
     a.H1 = ws->H1; a.gates = ws->gates; a.mixed = ws->mixed; a.stride = B->total_rows;
     a.D = B->D; a.C = B->C; a.slide0 = slide0; a.use_bits = use_bits;
     a.base_host = (n == 1 && B->row_off_host) ? B->row_off_host[slide0] : -1;
+    a.cand_mode = 0; a.stats = nullptr; a.sel_idx = nullptr;
+    if (B->flags & MOC_CAND_FROM_STATS) {
+        MOC_REQUIRE(B->stats && B->sel_idx, "moc_meta_forward: MOC_CAND_FROM_STATS needs the batch's stats and sel_idx");
+        a.cand_mode = (B->flags & MOC_STATS_COMPACT) ? 2 : 1;
+        a.stats = B->stats; a.sel_idx = B->sel_idx;
+    }
     dim3 grid(moc_cdiv(s_bound(B), 16), n);
     if (n >= 4 && B->dtype != MOC_F32 && (B->D * 2) % 512 == 0) {       // many slides at once (evaluation)
         dim3 g64(moc_cdiv(s_bound(B), 64), n);
@@ -1780,6 +1815,7 @@ extern "C" int moc_mix_fixed(const moc_batch_t* B, const moc_meta_ws_t* ws, int 
                              moc_stream_t stream) {
     if (int rc = moc_check_batch(B, "moc_mix_fixed")) return rc;
     MOC_REQUIRE(ws && ws->mixed && B->n_sel && B->cand, "moc_mix_fixed: null work array");
+    MOC_REQUIRE(!(B->flags & MOC_CAND_FROM_STATS), "moc_mix_fixed: a MOC_CAND_FROM_STATS batch has no materialised candidate scores");
     MOC_REQUIRE(slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_mix_fixed: bad slide range");
     MOC_REQUIRE(mode >= 0 && mode <= 2, "moc_mix_fixed: mode %d not in {0 avg, 1 sum, 2 max}", mode);
     FwdArgs a = {};

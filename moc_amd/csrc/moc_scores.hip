@@ -124,6 +124,7 @@ struct ScoresArgs {
     int D, C, Ce, NT;
     int tpw;                 // 16-row tiles per wave (1 when NT > 1)
     float oscale;            // products -> logits: 1, or 2^-14 for the scaled fp16 image
+    int compact;             // MOC_STATS_COMPACT: logits[C] | m1 | 1/den | gap | bg_sum | bg_max (no softmax columns)
 };
 
 // one lane per row: reads the 16 x Ctp tile the wave just wrote, emits the statistics
@@ -137,11 +138,24 @@ __device__ __forceinline__ void row_epilogue(const ScoresArgs& a, const float* t
         const float v = r[c];
         if (v > m1) { m2 = m1; m1 = v; } else if (v > m2) { m2 = v; }
     }
-    float den = 0.f;
-    for (int c = 0; c < C; ++c) den += expf(r[c] - m1);
     float bsum = 0.f, bmax = -INFINITY;
     for (int c = C; c < Ce; ++c) { const float v = r[c]; bsum += v; bmax = fmaxf(bmax, v); }
     float* s = a.stats + slot_base + slot;
+    if (a.compact) {
+        // the consumers re-form softmax[c] = exp2((v - m1) log2 e) * (1 / den): den is summed from those very terms
+        float den = 0.f;
+        for (int c = 0; c < C; ++c) den += __builtin_amdgcn_exp2f((r[c] - m1) * 1.44269504088896340736f);
+        for (int c = 0; c < C; ++c) s[(int64_t)c * a.stride] = r[c];
+        s[(int64_t)C * a.stride] = m1;
+        s[(int64_t)(C + 1) * a.stride] = 1.f / den;
+        s[(int64_t)(C + 2) * a.stride] = fabsf(m1 - m2);
+        s[(int64_t)(C + 3) * a.stride] = bsum;
+        s[(int64_t)(C + 4) * a.stride] = bmax;
+        a.sel_flag[slot_base + slot] = 0;
+        return;
+    }
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(r[c] - m1);
     for (int c = 0; c < C; ++c) {
         const float v = r[c];
         s[(int64_t)c * a.stride] = v;
@@ -229,6 +243,21 @@ __device__ __forceinline__ void row_stats_emit(const ScoresArgs& a, const float 
     float* sv = a.stats + slot_base;
     float* sp = sv + (int64_t)C * stride;
     const unsigned off = (unsigned)((int64_t)part * stride + (row0 + row));
+    if (a.compact) {
+        // C + 5 columns: the logits, then m1 | 1/den | gap | bg_sum | bg_max.  The softmax columns are what the selector
+        // and the candidate gather re-form from (v, m1, 1/den) with exactly the arithmetic above: e * rden.
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            if (q < qc) sv[off] = v[q];
+            sv += 4 * stride;
+        }
+        float* st = a.stats + slot_base + (int64_t)C * stride + (row0 + row);
+        if (part == 0) { st[0] = m1; st[2 * stride] = fabsf(m1 - m2); }
+        else if (part == 1) { st[stride] = rden; st[3 * stride] = bsum; }
+        else if (part == 2) st[4 * stride] = bmax;
+        else a.sel_flag[slot_base + row0 + row] = 0;
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         if (q < qc) {
@@ -1015,6 +1044,7 @@ static int scores_impl(const moc_batch_t* B, const void* bank, moc_stream_t stre
     a.sel_flag = B->sel_flag;
     a.stride = B->total_rows;
     a.D = B->D; a.C = B->C; a.Ce = B->Ce; a.NT = bank_nt(B->Ce);
+    a.compact = (B->flags & MOC_STATS_COMPACT) ? 1 : 0;
     const bool bf = B->dtype != MOC_F32;          // 16-bit storage (bf16 or fp16): 3-term image, K = 32 per MFMA
     const bool f16 = B->dtype == MOC_F16;
     a.oscale = f16 ? 1.f / MOC_F16_BANK_SCALE : 1.f;

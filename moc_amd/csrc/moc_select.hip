@@ -79,7 +79,24 @@ struct SelectArgs {
     int64_t stride;
     int C, topj;
     uint32_t discard_bits;
+    int compact;             // MOC_STATS_COMPACT layout: logits[C] | m1 | 1/den | gap | bg_sum | bg_max
 };
+
+
+// order-preserving key of selector column kc (0..C-1 psi_p, C..2C-1 psi_sigma, 2C psi_delta, 2C+1 psi_beta: smallest
+// background sum first) at slot i of a slide; `s` = stats + first slot of the slide
+__device__ __forceinline__ uint32_t sel_key(const SelectArgs& a, const float* s, int kc, int i) {
+    const int C = a.C;
+    const int64_t st = a.stride;
+    if (!a.compact) {
+        const uint32_t u = moc_key_desc(s[(int64_t)kc * st + i]);
+        return kc == 2 * C + 1 ? ~u : u;
+    }
+    if (kc < C) return moc_key_desc(s[(int64_t)kc * st + i]);
+    if (kc < 2 * C) return moc_key_desc(moc_softmax_from(s[(int64_t)(kc - C) * st + i], s[(int64_t)C * st + i], s[(int64_t)(C + 1) * st + i]));
+    if (kc == 2 * C) return moc_key_desc(s[(int64_t)(C + 2) * st + i]);
+    return ~moc_key_desc(s[(int64_t)(C + 3) * st + i]);
+}
 
 // grid (2C+2, n_slides)
 __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
@@ -96,10 +113,14 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
         for (int i = threadIdx.x; i < nk; i += blockDim.x) flag[i] = 1;
         return;
     }
-    // psi_beta ranks by the SMALLEST background sum: invert the key order
-    const float* col = a.stats + (int64_t)(sel == 3 ? 2 * C + 1 : kc) * a.stride + base;
+    // (psi_beta ranks by the SMALLEST background sum: its key order is inverted)
+    const float* srow = a.stats + base;
+    const bool direct = !a.compact || sel != 1;            // one stored column is the key (everything but compact psi_sigma)
+    const float* col = srow + (int64_t)(!a.compact ? kc : sel == 0 ? kc : sel == 2 ? C + 2 : sel == 3 ? C + 3 : kc - C) * a.stride;
+    const float* cm1 = srow + (int64_t)C * a.stride;
+    const float* crd = srow + (int64_t)(C + 1) * a.stride;
     const uint32_t flip = sel == 3 ? 0xFFFFFFFFu : 0u;
-    auto keyfn = [&](int i) { return moc_key_desc(col[i]) ^ flip; };
+    auto keyfn = [&](int i) { return direct ? (moc_key_desc(col[i]) ^ flip) : moc_key_desc(moc_softmax_from(col[i], cm1[i], crd[i])); };
     int take, ties;
     // ---- topj <= 1024: the topj-th largest of the 1024 per-thread maxima is a lower bound T0 of the topj-th largest
     // key (topj threads hold a key >= T0), so only keys >= T0 can be selected: a few hundred of 15,000.  They go to
@@ -155,6 +176,290 @@ __global__ __launch_bounds__(1024) void select_kernel(SelectArgs a) {
     }
 }
 
+
+// ---- wide banks: one workgroup per (slide, group of columns) -------------------------------------------------------
+// select_kernel gives every one of the 2C+2 columns of a slide a workgroup of its own: at thirty classes 62 workgroups
+// per slide, each a chain of ~40 barriers (two four-pass radix selects) around two sweeps of 15 keys per thread -- 541 us
+// for 202 slides, the latency of 12,500 short workgroups, not bytes.  Here a workgroup takes SG_COLS columns of a slide
+// through the SAME barriers: per-thread maxima of all its columns in one sweep, ONE four-pass radix select over the
+// SG_COLS x 1024 maxima (a histogram per column, a wave per column for the scans), one sweep that lists the keys above
+// each column's bound, one four-pass select over the lists, marks.  (Third form: the candidates of all the group's columns
+// share ONE pool of tagged entries -- 64 KiB instead of eight 16-KiB lists, so two workgroups fit a CU and one's barriers
+// and load latencies hide behind the other's work.)  (Round 3, second form: the bound comes from a SAMPLE of
+// 1024 slots instead of a full sweep of per-thread maxima -- the slide's statistics are read once, not twice.)  Columns are ordered (psi_p[c], psi_sigma[c]) pairs,
+// then psi_delta, psi_beta: with the compact statistics a pair shares its loads (v[c]; m1 and 1/den once per row).
+// Workgroups of one slide are dealt to one XCD (dispatch order: consecutive multiples of 8), so the row-wide columns
+// and the second sweep are L2 hits.  Rare cases -- a list that overflows, ties across the boundary that need the
+// column order -- take the per-column path (select_column_general) inside the same workgroup.
+constexpr int SG_COLS = 8;          // columns per workgroup
+constexpr int SG_POOL = 8192;       // tagged candidate entries of all the group's columns together (64 KiB; = 8 x 1024 samples)
+constexpr int SG_LDS_BYTES = SG_POOL * 8 + SG_COLS * 256 * 4 + 2048;      // 75,776: two workgroups per CU
+
+// general exact top-j of ONE column (the tail of select_kernel): radix select over the column, ties lowest row first
+template <typename KeyFn>
+__device__ __forceinline__ void select_column_general(KeyFn keyfn, int nk, int topj, uint8_t* flag, int* hist, int* wave_tot) {
+    int take, ties;
+    const uint32_t T = block_radix_select(keyfn, nk, topj, hist, &take, &ties);
+    if (take == ties) {
+        for (int i = threadIdx.x; i < nk; i += blockDim.x)
+            if (keyfn(i) >= T) flag[i] = 1;
+        return;
+    }
+    int running = 0;
+    for (int c0 = 0; c0 < nk; c0 += blockDim.x) {
+        const int i = c0 + threadIdx.x;
+        const uint32_t u = i < nk ? keyfn(i) : 0u;
+        const bool tie = i < nk && u == T;
+        int tot;
+        const int pos = moc_block_flag_scan(tie, wave_tot, &tot);
+        if (i < nk && (u > T || (tie && running + pos < take))) flag[i] = 1;
+        running += tot;
+    }
+}
+
+// The want-th largest key of each of up to SG_COLS key sets at once.  The sets live in ONE pool of tagged entries
+// (key << 32 | set << 29 | payload): an entry is counted into its own set's histogram, so a pass costs one LDS read and one
+// LDS atomic per entry whatever the number of sets.  Per-set state in LDS (st: [SG_COLS][8] ints: 0 prefix, 1 remaining,
+// 2 keys tied at the boundary digit, 3 total keys of the set, 4 ok).  hist: [SG_COLS][256].  Ends in a barrier.
+// Afterwards st[q][0] = the want-th largest key T, st[q][1] = how many keys equal to T belong to the top `want`,
+// st[q][2] = how many keys equal T, st[q][4] = 0 when the set holds fewer than `want` keys (then the rest is undefined).
+__device__ __forceinline__ void pool_radix_select(const unsigned long long* pool, int n, unsigned active, int want, int* hist, int* st) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < SG_COLS) {
+        int* sq = st + threadIdx.x * 8;
+        sq[0] = 0; sq[1] = want; sq[2] = 0; sq[3] = 0; sq[4] = (active >> threadIdx.x) & 1;
+    }
+    uint32_t pmask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < SG_COLS * 256; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const unsigned long long e = pool[i];
+            const int q = (int)(e >> 29) & 7;
+            const uint32_t u = (uint32_t)(e >> 32);
+            if ((u & pmask) == (uint32_t)st[q * 8]) atomicAdd(&hist[q * 256 + ((u >> shift) & 255)], 1);
+        }
+        __syncthreads();
+        if (wave < SG_COLS && st[wave * 8 + 4]) {                             // wave q scans set q's histogram
+            const int q = wave, L = lane;
+            const int* hq = hist + q * 256;
+            const int h0 = hq[4 * L], h1 = hq[4 * L + 1], h2 = hq[4 * L + 2], h3 = hq[4 * L + 3];
+            int suf = h0 + h1 + h2 + h3;                                      // becomes the sum over lanes >= L
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_down(suf, off, 64);
+                if (L + off < 64) suf += o;
+            }
+            const int total = __shfl(suf, 0, 64);
+            const int rem = st[q * 8 + 1];
+            if (rem > total) {                                                // fewer keys than wanted: the caller's other path
+                if (L == 0) st[q * 8 + 4] = 0;
+            } else {
+                const int above = suf - (h0 + h1 + h2 + h3);                  // keys in digits > 4L + 3
+                const int a3 = above, a2 = above + h3, a1 = a2 + h2, a0 = a1 + h1;
+                int d = -1, ab = 0, hd = 0;
+                if (a3 < rem && rem <= a3 + h3) { d = 4 * L + 3; ab = a3; hd = h3; }
+                else if (a2 < rem && rem <= a2 + h2) { d = 4 * L + 2; ab = a2; hd = h2; }
+                else if (a1 < rem && rem <= a1 + h1) { d = 4 * L + 1; ab = a1; hd = h1; }
+                else if (a0 < rem && rem <= a0 + h0) { d = 4 * L; ab = a0; hd = h0; }
+                if (d >= 0) {
+                    st[q * 8] |= d << shift;
+                    st[q * 8 + 1] = rem - ab;
+                    st[q * 8 + 2] = hd;
+                    if (shift == 24) st[q * 8 + 3] = total;
+                }
+            }
+        }
+        __syncthreads();
+        pmask |= 255u << shift;
+    }
+}
+
+// grid (groups * slides rounded up to 8), 1024 threads, SG_LDS_BYTES of dynamic LDS (two workgroups per CU)
+template <int SG_ROWS, int MINW>
+__global__ __launch_bounds__(1024, MINW) void select_group_kernel(SelectArgs a, int groups, int n_slides) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* pool = reinterpret_cast<unsigned long long*>(smem);             // [SG_POOL] tagged entries
+    int* hist = reinterpret_cast<int*>(smem + (size_t)SG_POOL * 8);                     // [SG_COLS][256]
+    int* st = hist + SG_COLS * 256;                                                     // [SG_COLS][8]
+    int* n_pool = st + SG_COLS * 8;                                                     // [1] (+3 pad)
+    int* wave_tot = n_pool + 4;                                                         // [20]
+    int* hist1 = wave_tot + 20;                                                         // [260] for the per-column path
+    const int lane = threadIdx.x & 63;
+    // the workgroups of one slide on one XCD: linear ids L, L + 8, L + 16, ... share an XCD under round-robin dispatch
+    // (speed only).  L = xcd + 8 * s: s-th workgroup of that XCD -> slide (s / groups) * 8 + xcd, group s % groups
+    const int L = blockIdx.x, xcd = L & 7, sq = L >> 3;
+    const int b = (sq / groups) * 8 + xcd, grp = sq % groups;
+    if (b >= n_slides) return;                             // (the grid covers the slides rounded up to a multiple of 8)
+    const int C = a.C, ncol = 2 * C + 2;
+    const int p0 = grp * SG_COLS;
+    const int nq = min(SG_COLS, ncol - p0);
+    // ---- what this group reads and how a key is formed from it.  Position p of the pairing order is selector column
+    // kc = c (p = 2c: psi_p), C + c (p = 2c + 1: psi_sigma), then 2C (psi_delta), 2C + 1 (psi_beta).  `src` = the rows of
+    // `stats` this group loads per slot (at most 8), column q's key = form[q] of its source:
+    //   0: key(v)    1: key(exp2((v - m1) log2 e) / den)  [compact layout]    2: ~key(v)  (psi_beta: smallest first)
+    // Slots are fixed by position (no searching, no indexed registers): full layout -- slot q holds column q's own row;
+    // compact layout -- slots 0, 1 = m1, 1/den, slot 2 + (q >> 1) = v[c] of the pair at columns q, q + 1 (or psi_delta's
+    // gap), one slot further psi_beta's background sum (it is always the last column, right behind psi_delta).
+    int src[SG_COLS], form[SG_COLS], kcs[SG_COLS];
+    unsigned active = 0;
+#pragma unroll
+    for (int q = 0; q < SG_COLS; ++q) { src[q] = -1; form[q] = 0; kcs[q] = 0; }
+#pragma unroll
+    for (int q = 0; q < SG_COLS; ++q) {
+        if (q >= nq) continue;
+        const int p = p0 + q;
+        const int kc = p < 2 * C ? ((p & 1) ? C + (p >> 1) : (p >> 1)) : p;
+        kcs[q] = kc;
+        const int sel = kc < C ? 0 : kc < 2 * C ? 1 : kc == 2 * C ? 2 : 3;
+        if (a.discard_bits >> sel & 1u) continue;
+        active |= 1u << q;
+        form[q] = (a.compact && sel == 1) ? 1 : sel == 3 ? 2 : 0;
+    }
+    if (!active) return;
+    if (!a.compact) {
+#pragma unroll
+        for (int q = 0; q < SG_COLS; ++q) if (active >> q & 1u) src[q] = kcs[q];
+    } else {
+        bool any_sigma = false;
+#pragma unroll
+        for (int q = 0; q < SG_COLS; ++q) any_sigma = any_sigma || ((active >> q & 1u) && form[q] == 1);
+        if (any_sigma) { src[0] = C; src[1] = C + 1; }
+#pragma unroll
+        for (int q = 0; q < SG_COLS; ++q) {
+            if (!(active >> q & 1u)) continue;
+            const int kc = kcs[q];
+            const int row = kc < C ? kc : kc < 2 * C ? kc - C : kc == 2 * C ? C + 2 : C + 3;
+            const int slot = 2 + (q >> 1) + (form[q] == 2 ? 1 : 0);           // (q compile-time: a fixed register per case)
+#pragma unroll
+            for (int t = 2; t < SG_COLS; ++t) if (slot == t) src[t] = row;    // (a pair writes the same row twice)
+        }
+    }
+    const int64_t base = a.row_off[b];
+    const int nk = a.n_kept ? a.n_kept[b] : (int)(a.row_off[b + 1] - base);
+    if (nk <= 0) return;
+    uint8_t* flag = a.sel_flag + base;
+    const float* srow = a.stats + base;
+    if (a.topj >= nk) {                                    // maxj = min(topj, N'): every kept row is selected
+        for (int i = threadIdx.x; i < nk; i += 1024) flag[i] = 1;
+        return;
+    }
+    auto load_row = [&](int i, float (&r)[SG_COLS]) {      // the group's sources at slot i: independent loads
+#pragma unroll
+        for (int t = 0; t < SG_COLS; ++t) r[t] = src[t] >= 0 ? srow[(int64_t)src[t] * a.stride + i] : 0.f;
+    };
+    auto keys_from = [&](const float (&r)[SG_COLS], uint32_t (&k)[SG_COLS]) {
+#pragma unroll
+        for (int q = 0; q < SG_COLS; ++q) {
+            k[q] = 0;
+            if (!(active >> q & 1u)) continue;
+            constexpr int LAST = SG_COLS - 1;
+            const int sa = 2 + (q >> 1), sb = sa + 1 < LAST ? sa + 1 : LAST;
+            float v = a.compact ? (form[q] == 2 ? r[sb] : r[sa < LAST ? sa : LAST]) : r[q];
+            if (form[q] == 1) v = moc_softmax_from(v, r[0], r[1]);            // (slots 0, 1: m1 and 1/den)
+            const uint32_t u = moc_key_desc(v);
+            k[q] = form[q] == 2 ? ~u : u;
+        }
+    };
+    unsigned todo = 0;                                     // columns left to the per-column path
+    if (nk > 2048) {
+        // ---- a bound T0[q] per column from a SAMPLE of 1024 evenly spaced slots: the ks-th largest sampled key with
+        // ks = twice the share the wanted topj have in the slide, so that about 2 topj keys lie at or above it (for
+        // topj = 400 of 15,000: 810 +- 110).  The bound only decides how many candidates there are; the selection
+        // itself is exact: a column must end up with at least topj candidates in the pool (else, ~1e-4 of the columns,
+        // the per-column path).
+        int ks = (int)((2048ll * a.topj + nk - 1) / nk) + 4;
+        ks = ks > 1024 ? 1024 : ks;
+        {
+            const int i = (int)(((int64_t)threadIdx.x * nk) >> 10);
+            float r[SG_COLS];
+            uint32_t k[SG_COLS];
+            load_row(i, r);
+            keys_from(r, k);
+#pragma unroll
+            for (int q = 0; q < SG_COLS; ++q) pool[q * 1024 + threadIdx.x] = ((unsigned long long)k[q] << 32) | ((unsigned long long)q << 29);
+        }
+        __syncthreads();
+        pool_radix_select(pool, SG_COLS * 1024, active, ks, hist, st);
+        uint32_t T0[SG_COLS];
+#pragma unroll
+        for (int q = 0; q < SG_COLS; ++q) T0[q] = (uint32_t)st[q * 8];
+        if (threadIdx.x == 0) n_pool[0] = 0;
+        __syncthreads();                                   // everyone has its bounds; the pool is free again
+        // ---- ONE sweep over the slide: the keys at or above their column's bound go to the pool, tagged with column
+        // and slot.  SG_ROWS slots per thread in flight (SG_ROWS x up to 8 independent loads) before the first key is formed;
+        // one LDS atomic per wave and slot batch (the wave's hits are placed by a prefix sum over its lanes).
+        for (int ib = 0; ib < nk; ib += SG_ROWS * 1024) {          // (uniform trip count: the body shuffles across the wave)
+            const int i0 = ib + (int)threadIdx.x;
+            float r[SG_ROWS][SG_COLS];
+#pragma unroll
+            for (int u = 0; u < SG_ROWS; ++u) {
+                const int i = i0 + u * 1024;
+                load_row(i < nk ? i : nk - 1, r[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < SG_ROWS; ++u) {
+                const int i = i0 + u * 1024;
+                uint32_t k[SG_COLS];
+                keys_from(r[u], k);
+                unsigned hits = 0;
+                if (i < nk) {
+#pragma unroll
+                    for (int q = 0; q < SG_COLS; ++q) hits |= ((active >> q & 1u) && k[q] >= T0[q]) ? 1u << q : 0u;
+                }
+                const int cnt = __popc(hits);
+                int inc = cnt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(inc, off, 64);
+                    if (lane >= off) inc += o;
+                }
+                const int wtot = __shfl(inc, 63, 64);
+                if (wtot == 0) continue;                   // (uniform)
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(n_pool, wtot);
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                int pos = wbase + inc - cnt;
+#pragma unroll
+                for (int q = 0; q < SG_COLS; ++q) {
+                    if (hits >> q & 1u) {
+                        if (pos < SG_POOL) pool[pos] = ((unsigned long long)k[q] << 32) | ((unsigned long long)q << 29) | (unsigned)i;
+                        ++pos;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int np = n_pool[0];
+        if (np <= SG_POOL) {                               // (uniform)
+            pool_radix_select(pool, np, active, a.topj, hist, st);
+            // a column is settled when it had at least topj candidates and no tie straddles the boundary
+            for (int i = threadIdx.x; i < np; i += 1024) {
+                const unsigned long long e = pool[i];
+                const int q = (int)(e >> 29) & 7;
+                const int* sq = st + q * 8;
+                if (sq[4] && sq[1] == sq[2] && (uint32_t)(e >> 32) >= (uint32_t)sq[0]) flag[(uint32_t)e & 0x1FFFFFFFu] = 1;
+            }
+#pragma unroll
+            for (int q = 0; q < SG_COLS; ++q)
+                if ((active >> q & 1u) && !(st[q * 8 + 4] && st[q * 8 + 1] == st[q * 8 + 2])) todo |= 1u << q;
+        } else {
+            todo = active;                                 // the pool overflowed: which column lost entries is not known
+        }
+        if (!todo) return;
+        __syncthreads();
+    } else {
+        todo = active;                                     // short slides: the per-column path (a sample says little)
+    }
+    // ---- per-column path for what is left (short slides, too few candidates, boundary ties that need the row order)
+#pragma unroll
+    for (int q = 0; q < SG_COLS; ++q) {
+        if (!(todo >> q & 1u)) continue;                   // uniform
+        const int kc = kcs[q];
+        select_column_general([&](int i) { return sel_key(a, srow, kc, i); }, nk, a.topj, flag, hist1, wave_tot);
+        __syncthreads();
+    }
+}
+
 struct CompactArgs {
     const float* stats;
     const int64_t* row_off;
@@ -171,7 +476,17 @@ struct CompactArgs {
     int cand_inline;                // compact_kernel copies the candidate columns itself
     int64_t stride;
     int C, row_bytes;
+    int compact;                    // MOC_STATS_COMPACT layout of `stats`
 };
+
+// candidate score k (0..C-1 s_p, C..2C-1 s_sigma, 2C s_delta, 2C+1 s_beta = MAX background logit: main_moc.py:359-366)
+// of the row at `s` (= stats + slot), either layout
+__device__ __forceinline__ float cand_value(const float* s, int64_t stride, int C, int k, int compact) {
+    if (!compact) return s[(int64_t)(k == 2 * C + 1 ? 2 * C + 2 : k) * stride];
+    if (k < C) return s[(int64_t)k * stride];
+    if (k < 2 * C) return moc_softmax_from(s[(int64_t)(k - C) * stride], s[(int64_t)C * stride], s[(int64_t)(C + 1) * stride]);
+    return s[(int64_t)(k == 2 * C ? C + 2 : C + 4) * stride];
+}
 
 // grid (n_slides)
 __global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a) {
@@ -217,7 +532,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(CompactArgs a) {
             float v[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k)
-                if (k < 2 * C + 2) v[k] = s[(int64_t)(k == 2 * C + 1 ? 2 * C + 2 : k) * a.stride];   // the last one is s_beta = max background
+                if (k < 2 * C + 2) v[k] = cand_value(s, a.stride, C, k, a.compact);   // the last one is s_beta = max background
 #pragma unroll
             for (int k = 0; k < 10; ++k)
                 if (k < 2 * C + 2) c[(int64_t)k * a.stride] = v[k];
@@ -240,6 +555,17 @@ __global__ __launch_bounds__(256) void cand_gather_kernel(CompactArgs a) {
     const int k_lo = blockIdx.y * CAND_COLS, k_hi = min(k_lo + CAND_COLS, 2 * C + 2);
     const float* s = a.stats + base + i;
     float* c = a.cand + base + o;
+    if (a.compact) {                                   // s_sigma re-formed from (v, m1, 1/den); m1 and 1/den once per thread
+        const float m1 = s[(int64_t)C * a.stride], rden = s[(int64_t)(C + 1) * a.stride];
+        for (int k = k_lo; k < k_hi; ++k) {
+            float v;
+            if (k < C) v = s[(int64_t)k * a.stride];
+            else if (k < 2 * C) v = moc_softmax_from(s[(int64_t)(k - C) * a.stride], m1, rden);
+            else v = s[(int64_t)(k == 2 * C ? C + 2 : C + 4) * a.stride];
+            c[(int64_t)k * a.stride] = v;
+        }
+        return;
+    }
     for (int k = k_lo; k < k_hi; ++k)                  // candidate k <- statistic k; the last one is s_beta = max background
         c[(int64_t)k * a.stride] = s[(int64_t)(k == 2 * C + 1 ? 2 * C + 2 : k) * a.stride];
 }
@@ -528,7 +854,31 @@ extern "C" int moc_select(const moc_batch_t* B, moc_stream_t stream) {
     a.stats = B->stats; a.row_off = B->row_off; a.n_kept = B->mask ? B->n_kept : nullptr;
     a.sel_flag = B->sel_flag; a.stride = B->total_rows; a.C = B->C; a.topj = B->topj;
     a.discard_bits = B->discard_bits;
-    dim3 grid(2 * B->C + 2, B->n_slides);
+    a.compact = (B->flags & MOC_STATS_COMPACT) ? 1 : 0;
+    const int ncol = 2 * B->C + 2;
+    static const int force = getenv("MOC_SELECT_KERNEL") ? atoi(getenv("MOC_SELECT_KERNEL")) : 0;   // diagnostic: 1 per column, 2 grouped
+    if ((ncol > SG_COLS || force == 2) && force != 1 && !(B->flags & MOC_SELECT_PER_COLUMN) && B->topj <= 1024) {
+        // wide banks: one workgroup per slide and group of SG_COLS columns (select_group_kernel)
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)select_group_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)select_group_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)select_group_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_BYTES);
+            attr_set = true;
+        }
+        const int groups = moc_cdiv(ncol, SG_COLS);
+        const int n8 = (B->n_slides + 7) & ~7;             // a slide's workgroups share an XCD: see the kernel's id mapping
+        // <slots in flight per thread, waves per SIMD>: measured at 202 x 15,000 x 30 classes (scripts/bench_select.py):
+        // <1, 8> 394 us (59 registers, two workgroups per CU), <2, 8> 402 (64 registers, 6 spilled), <4, 4> 459 (one
+        // workgroup per CU); one workgroup per column (select_kernel): 965
+        static const int variant = getenv("MOC_SELECT_VARIANT") ? atoi(getenv("MOC_SELECT_VARIANT")) : 2;
+        if (variant == 1) select_group_kernel<4, 4><<<dim3(groups * n8), 1024, SG_LDS_BYTES, (hipStream_t)stream>>>(a, groups, B->n_slides);
+        else if (variant == 0) select_group_kernel<2, 8><<<dim3(groups * n8), 1024, SG_LDS_BYTES, (hipStream_t)stream>>>(a, groups, B->n_slides);
+        else select_group_kernel<1, 8><<<dim3(groups * n8), 1024, SG_LDS_BYTES, (hipStream_t)stream>>>(a, groups, B->n_slides);
+        MOC_CHECK_LAUNCH("moc_select(group)");
+        return MOC_OK;
+    }
+    dim3 grid(ncol, B->n_slides);
     select_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(a);
     MOC_CHECK_LAUNCH("moc_select");
     return MOC_OK;
@@ -544,10 +894,11 @@ extern "C" int moc_gather_candidates(const moc_batch_t* B, void* selected_feat, 
     a.sel_flag = B->sel_flag; a.sel_idx = B->sel_idx; a.sel_row = B->sel_row; a.n_sel = B->n_sel;
     a.cand = B->cand; a.X = (const unsigned char*)B->X; a.selected_feat = (unsigned char*)selected_feat;
     a.stride = B->total_rows; a.C = B->C; a.row_bytes = B->D * moc_elem_size(B->dtype);
+    a.compact = (B->flags & MOC_STATS_COMPACT) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     a.cand_inline = B->C <= 4;
     compact_kernel<<<B->n_slides, 1024, 0, s>>>(a);
-    if (!a.cand_inline) {
+    if (!a.cand_inline && !(B->flags & MOC_CAND_FROM_STATS)) {     // (evaluation: the forward reads the statistics itself)
         MOC_CHECK_LAUNCH("moc_gather_candidates(compact)");
         cand_gather_kernel<<<dim3(moc_cdiv(B->max_rows, 256), moc_cdiv(2 * B->C + 2, CAND_COLS), B->n_slides), 256, 0, s>>>(a);
     }
@@ -564,7 +915,7 @@ extern "C" int moc_gather_candidates(const moc_batch_t* B, void* selected_feat, 
 extern "C" int moc_pack_selected(const moc_batch_t* B, int slide0, int n, int cap, void* feat_out, float* cand_out,
                                  moc_stream_t stream) {
     if (int rc = moc_check_batch(B, "moc_pack_selected")) return rc;
-    MOC_REQUIRE(B->sel_row && B->n_sel && B->cand, "moc_pack_selected: batch has no phase-A outputs");
+    MOC_REQUIRE(B->sel_row && B->n_sel && B->cand && !(B->flags & MOC_CAND_FROM_STATS), "moc_pack_selected: batch has no phase-A outputs");
     MOC_REQUIRE(slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_pack_selected: bad slide range");
     MOC_REQUIRE(cap >= 1 && feat_out && cand_out, "moc_pack_selected: bad cap/outputs");
     PackArgs a;
@@ -580,7 +931,7 @@ extern "C" int moc_pack_selected(const moc_batch_t* B, int slide0, int n, int ca
 extern "C" int moc_pack_selected_rows(const moc_batch_t* B, int slide0, int n, int cap, void* feat_out, float* cand_out,
                                       int64_t out_rows, moc_stream_t stream) {
     if (int rc = moc_check_batch(B, "moc_pack_selected_rows")) return rc;
-    MOC_REQUIRE(B->sel_row && B->n_sel && B->cand, "moc_pack_selected_rows: batch has no phase-A outputs");
+    MOC_REQUIRE(B->sel_row && B->n_sel && B->cand && !(B->flags & MOC_CAND_FROM_STATS), "moc_pack_selected_rows: batch has no phase-A outputs");
     MOC_REQUIRE(slide0 >= 0 && n >= 1 && slide0 + n <= B->n_slides, "moc_pack_selected_rows: bad slide range");
     MOC_REQUIRE(cap >= 1 && out_rows >= 1 && feat_out && cand_out, "moc_pack_selected_rows: bad cap/outputs");
     PackArgs a;

@@ -23,6 +23,8 @@ HIDDEN = 64
 # starts later (the whole graph is enqueued before the doorbell), so stream launches stay the default.
 STEP_GRAPH = os.environ.get("MOC_STEP_GRAPH", "0") == "1"
 GRAPH_TABLE_STEPS = 4096        # Adam steps of coefficients kept on the device per table build
+CAND_FROM_STATS = os.environ.get("MOC_CAND_FROM_STATS", "1") != "0"   # evaluation: no materialised candidate columns (0: as in training)
+COMPACT_STATS = os.environ.get("MOC_COMPACT_STATS", "1") != "0"     # wide banks: C + 5 statistics per row (0: always 2C + 3)
 
 # bench.py sets this to a list: every batched score-pass launch then appends
 # (start_event, stop_event, algorithmic_bytes) recorded on the launch stream.
@@ -138,7 +140,7 @@ class SlideBatch:
             X=ptr(X), dtype=_dtype_code(X.dtype), D=self.D, total_rows=T, n_slides=n, max_rows=max(sizes),
             row_off=ptr(self.row_off), row_off_host=C.cast(self._row_off_c, C.c_void_p), x_off=ptr(self.x_off),
             mask=ptr(self.mask), C=self.C, Ce=self.Ce, topj=self.topj,
-            topk=self.topk, discard_bits=self.discard_bits, reserved=0, kept=ptr(self.kept),
+            topk=self.topk, discard_bits=self.discard_bits, flags=0, kept=ptr(self.kept),
             n_kept=ptr(self.n_kept), stats=ptr(self.stats), sel_flag=ptr(self.sel_flag),
             sel_idx=ptr(self.sel_idx), sel_row=ptr(self.sel_row), n_sel=ptr(self.n_sel), cand=ptr(self.cand))
         self._ws = None
@@ -168,8 +170,19 @@ class SlideBatch:
         self.c.max_rows = max(1, mk)
 
     # ---- phase A ----
-    def phase_a(self, bank: Bank):
+    def _layout(self, compact: bool, cand_from_stats: bool = False):
+        """Statistics layout of the next score pass and of what reads it (include/moc_hip.h MOC_STATS_COMPACT);
+        cand_from_stats: an evaluation pass -- the forward reads the candidate scores from the statistics, the
+        [2C+2, S] candidate columns of wide banks are never written (MOC_CAND_FROM_STATS)."""
+        self.c.flags = ((_lib.MOC_STATS_COMPACT if compact else 0) | (_lib.MOC_CAND_FROM_STATS if cand_from_stats else 0) |
+                        (self.c.flags & _lib.MOC_SELECT_PER_COLUMN))
+
+    def phase_a(self, bank: Bank, for_eval: bool = False):
         assert bank.D == self.D and bank.C == self.C and bank.Ce == self.Ce and bank.dtype == self.X.dtype
+        # wide banks: C + 5 statistics per row instead of 2C + 3 (the selector and the candidate gather re-form the
+        # softmax columns); phase A is the only reader of its own statistics, so the layout is its private choice.
+        # for_eval: only meta_forward follows (no train step, no ablation mix): candidates straight from the statistics
+        self._layout(COMPACT_STATS and self.Ce > 16, cand_from_stats=bool(for_eval) and CAND_FROM_STATS and self.C > 4)
         if SCORE_EVENTS is None:
             check(lib().moc_phase_a(C.byref(self.c), ptr(bank.image), _stream()), "moc_phase_a")
             return
@@ -181,6 +194,7 @@ class SlideBatch:
         self.gather_candidates()
 
     def scores(self, bank: Bank):
+        self._layout(False)                      # callers of scores() read `stats` themselves: the full layout
         check(lib().moc_mask_compact(C.byref(self.c), _stream()), "moc_mask_compact")
         check(lib().moc_scores(C.byref(self.c), ptr(bank.image), _stream()), "moc_scores")
 
@@ -238,7 +252,7 @@ class CompactBatch(SlideBatch):
         self.c = MocBatch(
             X=ptr(self.X), dtype=_dtype_code(dtype), D=self.D, total_rows=T, n_slides=self.n_slides, max_rows=cap,
             row_off=ptr(self.row_off), row_off_host=C.cast(self._row_off_c, C.c_void_p), x_off=None, mask=None,
-            C=self.C, Ce=self.Ce, topj=self.topj, topk=self.topk, discard_bits=0, reserved=0, kept=None, n_kept=None,
+            C=self.C, Ce=self.Ce, topj=self.topj, topk=self.topk, discard_bits=0, flags=0, kept=None, n_kept=None,
             stats=None, sel_flag=None, sel_idx=None, sel_row=ptr(self.sel_row), n_sel=ptr(self.n_sel), cand=ptr(self.cand))
         self._ws = None
 

@@ -609,7 +609,7 @@ def _eval_pass(loader, device, args, mode, model=None, pooling_func=None):
             tensors["pooled"].copy_(p)
             engine.loss_only(batch, lab, 0, n)
         else:
-            batch.phase_a(bank)
+            batch.phase_a(bank, for_eval=(mode == "eval"))
             if mode == "eval":
                 engine.meta_forward(batch, meta, 0, n, engine.eval_use_bits(args.discard_classifiers), keep_hidden=False)
             else:

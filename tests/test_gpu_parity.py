@@ -745,3 +745,83 @@ def test_full_size_wide_configs_match_oracle(dev, name, C, K, j, D, dtype, sizes
         pooled, _, losses = M._eval_pass(res, dev, args, "eval", model=model)
     np.testing.assert_allclose(pooled.numpy(), torch.cat(ref_pooled, 0).numpy(), atol=ATOL, err_msg=name)
     np.testing.assert_allclose(losses, ref_loss, atol=ATOL, err_msg=name)
+
+
+# ------------------------------------------------------------------ round 3: compact statistics, grouped selector
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,D,sizes,j", [(13, 512, [3000, 2500, 70], 100), (30, 512, [5000, 4100, 2049, 300], 400),
+                                        (30, 512, [2600, 2300], 1024), (64, 1024, [3000, 2200], 400), (20, 256, [2500], 50)])
+def test_compact_statistics_and_grouped_selector_give_the_same_bits(dev, dtype, C, D, sizes, j):
+    """Wide banks write C + 5 statistics per row and let the selector / candidate gather re-form the softmax columns
+    (include/moc_hip.h MOC_STATS_COMPACT), and take one workgroup per slide and group of eight columns (select_group_kernel)
+    instead of one per column.  Neither may change a bit: union flags, selected_index, n_sel and all 2C + 2 candidate
+    columns are compared with the full layout + per-column selector, masked and unmasked, incl. discarded selectors."""
+    E = _engine()
+    from moc_amd import _lib
+    if dtype == torch.float32 and C == 64:
+        pytest.skip("fp32 storage beyond four n-tiles takes the generic kernel (covered by its own shapes)")
+    W, We = synth.make_bank(333 + C, D, C)
+    bags, _ = synth.make_slide_set(4400 + C, sizes, D, We, C)
+    X = torch.cat(bags).to(dev).to(dtype).contiguous()
+    bank = E.Bank.get(W.to(dev), We.to(dev), dtype, dev)
+    g = torch.Generator().manual_seed(5)
+    mask = (torch.rand(sum(sizes), generator=g) > 0.5).to(torch.uint8)
+    for discard, m in (((), None), ((), mask), (("delta_softmax",), mask), (("topk", "bottomk"), None)):
+        outs = []
+        for compact, per_column in ((False, True), (True, False), (True, True), (False, False)):
+            b = E.SlideBatch(X, sizes, C, C + 4, j, 10, discard, mask=m)
+            b.c.flags = _lib.MOC_SELECT_PER_COLUMN if per_column else 0
+            keep = E.COMPACT_STATS
+            E.COMPACT_STATS = compact
+            try:
+                b.phase_a(bank)
+            finally:
+                E.COMPACT_STATS = keep
+            assert bool(b.c.flags & _lib.MOC_STATS_COMPACT) == compact
+            torch.cuda.synchronize()
+            outs.append((b.sel_flag.clone(), b.n_sel.clone(), b.sel_idx.clone(), b.cand.clone(), b.n_kept.clone() if m is not None else None))
+        ref = outs[0]
+        off = [0]
+        for n in sizes:
+            off.append(off[-1] + n)
+        for o in outs[1:]:
+            assert torch.equal(o[1], ref[1]), "n_sel differs"
+            for s_i in range(len(sizes)):
+                nk = int(ref[4][s_i]) if m is not None else sizes[s_i]
+                S = int(ref[1][s_i])
+                lo = off[s_i]
+                assert torch.equal(o[0][lo:lo + nk], ref[0][lo:lo + nk]), f"union flags of slide {s_i} differ"
+                assert torch.equal(o[2][lo:lo + S], ref[2][lo:lo + S]), f"selected_index of slide {s_i} differs"
+                assert torch.equal(o[3][:, lo:lo + S], ref[3][:, lo:lo + S]), f"candidate scores of slide {s_i} differ"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,sizes,j,discard", [(30, [3000, 2600, 2200, 500, 2049], 400, ()), (13, [2500, 2300, 2400, 2100], 100, ("delta_diff",)),
+                                              (5, [1500, 1400, 1300, 1200], 50, ())])
+def test_evaluation_reads_candidates_from_the_statistics_with_the_same_bits(dev, dtype, C, sizes, j, discard):
+    """Evaluation passes of wide banks never materialise the [2C+2, S] candidate columns (MOC_CAND_FROM_STATS): the forward
+    reads a selected row's scores from the score pass's statistics through sel_idx.  The pooled logits, losses and
+    predictions must be the bits of the pass that gathers the candidates first -- in both forward kernels (the 64-row
+    one for launches over >= 4 slides of 16-bit bags, the 16-row one otherwise)."""
+    M, E = _mm(), _engine()
+    W, We = synth.make_bank(70 + C, 512, C)
+    bags, labels = synth.make_slide_set(7000 + C, sizes, 512, We, C)
+    M.set_classifier_bank(W.to(dev), We.to(dev))
+    torch.manual_seed(4)
+    model = M.senet(512, 4).to(dev)
+    args = H.make_args(C, j, 10, discard)
+    outs = []
+    keep = E.CAND_FROM_STATS
+    try:
+        for on in (False, True):
+            E.CAND_FROM_STATS = on
+            res = M.ResidentBags(bags, labels, dev, dtype=dtype)
+            pooled, _, losses = M._eval_pass(res, dev, args, "eval", model=model)
+            batch = res.eval_plan(C, C + 4, j, 10, list(discard))["batch"]
+            from moc_amd import _lib
+            assert bool(batch.c.flags & _lib.MOC_CAND_FROM_STATS) == (on and C > 4)
+            outs.append((pooled.clone(), list(losses)))
+    finally:
+        E.CAND_FROM_STATS = keep
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    assert torch.isfinite(outs[0][0]).all()
