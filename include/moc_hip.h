@@ -60,7 +60,11 @@ enum { MOC_STATS_COMPACT = 1,
         * (C > 4) and moc_meta_forward reads a selected row's four scores (main_moc.py:359-366, :482-492) straight from
         * `stats` through sel_idx -- the same values.  Entry points that need `cand` itself (the train steps,
         * moc_mix_fixed, moc_pack_selected*) refuse such a batch. */
-       MOC_CAND_FROM_STATS = 4 };
+       MOC_CAND_FROM_STATS = 4,
+       /* moc_meta_forward over many slides: keep to 64 rows per workgroup (the default for launches of at least four
+        * slides with 1024 or more selectable rows on 16-bit bags is 256 rows per workgroup, rows by LDS-DMA); both give
+        * the bits of the one-slide kernel -- the bit exists so that tests can say so */
+       MOC_FORWARD_ROWS64 = 8 };
 
 /* bits of `discard_bits`, in the order of main_moc.py:341-350 */
 enum { MOC_SEL_TOPK = 1, MOC_SEL_DELTA_SOFTMAX = 2, MOC_SEL_DELTA_DIFF = 4, MOC_SEL_BOTTOMK = 8 };

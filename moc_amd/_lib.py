@@ -21,6 +21,7 @@ MOC_F32, MOC_BF16, MOC_F16 = 0, 1, 2
 MOC_STATS_COMPACT = 1
 MOC_SELECT_PER_COLUMN = 2
 MOC_CAND_FROM_STATS = 4
+MOC_FORWARD_ROWS64 = 8
 SEL_BITS = {"topk": 1, "delta_softmax": 2, "delta_diff": 4, "bottomk": 8}
 
 _p = C.c_void_p

@@ -4,6 +4,21 @@
 #include <stdint.h>
 #include "../../include/moc_hip.h"
 
+// No implicit fused multiply-adds anywhere in this library: a * b + c is a multiplication and an addition, each rounded,
+// as in the reference's PyTorch-CPU elementwise kernels (the gated mix main_moc.py:391-403, Adam's lerp / addcmul /
+// addcdiv); fused operations exist only where the source says fmaf.  hipcc's default (-ffp-contract=fast) fuses or not
+// per call site -- __fmul_rn / __fadd_rn are plain operators in this toolchain -- so two kernels holding the same
+// expression could differ in the last bit (the 256-row evaluation forward did, against the 16-row one, in `mixed`).
+#pragma clang fp contract(off)
+// The single operations the kernels spell out where the reference's rounding sequence matters.  NOT hip's __fmul_rn /
+// __fadd_rn: those are inline functions of a system header, compiled under ITS contraction mode (fast), so that after
+// inlining `__fadd_rn(v, __fmul_rn(a, b))` may still become one fma -- kernel by kernel, as the optimiser sees fit.
+static __device__ __forceinline__ float moc_fadd(float a, float b) { return a + b; }
+static __device__ __forceinline__ float moc_fsub(float a, float b) { return a - b; }
+static __device__ __forceinline__ float moc_fmul(float a, float b) { return a * b; }
+static __device__ __forceinline__ float moc_fdiv(float a, float b) { return a / b; }
+static __device__ __forceinline__ float moc_fsqrt(float a) { return __builtin_sqrtf(a); }
+
 #define MOC_WAVE 64
 #define MOC_HIDDEN 64
 

@@ -45,11 +45,11 @@ struct AdamCoef {
 //   g = g + wd*p ; m.lerp_(g, 1-b1) ; v.mul_(b2).addcmul_(g, g, 1-b2)
 //   denom = sqrt(v)/bc2_sqrt + eps ; p.addcdiv_(m, denom, -step_size)
 __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, const AdamCoef& k) {
-    g = __fadd_rn(g, __fmul_rn(k.wd, p));
-    m = __fadd_rn(m, __fmul_rn(k.one_minus_b1, __fsub_rn(g, m)));
-    v = __fadd_rn(__fmul_rn(v, k.beta2), __fmul_rn(__fmul_rn(k.one_minus_b2, g), g));
-    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), k.bc2_sqrt), k.eps);
-    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(k.neg_step_size, m), denom));
+    g = moc_fadd(g, moc_fmul(k.wd, p));
+    m = moc_fadd(m, moc_fmul(k.one_minus_b1, moc_fsub(g, m)));
+    v = moc_fadd(moc_fmul(v, k.beta2), moc_fmul(moc_fmul(k.one_minus_b2, g), g));
+    const float denom = moc_fadd(moc_fdiv(moc_fsqrt(v), k.bc2_sqrt), k.eps);
+    p = moc_fadd(p, moc_fdiv(moc_fmul(k.neg_step_size, m), denom));
 }
 
 // ------------------------------------------------------------------ forward
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float pre = F16 ? acc[i] * (1.f / MOC_F16_W1_SCALE) : acc[i];     // exact power-of-two scaling
-            Hs[(lane >> 4) * 4 + i][hcol] = fmaxf(__fadd_rn(pre, bias), 0.f);
+            Hs[(lane >> 4) * 4 + i][hcol] = fmaxf(moc_fadd(pre, bias), 0.f);
         }
         W2s[threadIdx.x] = w2_pre;
     }
@@ -278,10 +278,10 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
             cand_row_scores(a, cd, s2, s3);
         }
         float v = 0.f;   // 0 + x == x exactly, so this is the reference's running sum in both modes
-        if (a.use_bits & 1u) v = __fadd_rn(v, __fmul_rn(Gs[r][0], s0));
-        if (a.use_bits & 2u) v = __fadd_rn(v, __fmul_rn(Gs[r][1], s1));
-        if (a.use_bits & 4u) v = __fadd_rn(v, __fmul_rn(Gs[r][2], s2));
-        if (a.use_bits & 8u) v = __fadd_rn(v, __fmul_rn(Gs[r][3], s3));
+        if (a.use_bits & 1u) v = moc_fadd(v, moc_fmul(Gs[r][0], s0));
+        if (a.use_bits & 2u) v = moc_fadd(v, moc_fmul(Gs[r][1], s1));
+        if (a.use_bits & 4u) v = moc_fadd(v, moc_fmul(Gs[r][2], s2));
+        if (a.use_bits & 8u) v = moc_fadd(v, moc_fmul(Gs[r][3], s3));
         a.mixed[(int64_t)c * a.stride + base + row0 + r] = v;
     }
     MOC_STAMP(2);
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void meta_forward64_kernel(FwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float pre = F16 ? acc[rt][i] * (1.f / MOC_F16_W1_SCALE) : acc[rt][i];     // exact power-of-two scaling
-                Hs[rt * 16 + (lane >> 4) * 4 + i][hcol] = fmaxf(__fadd_rn(pre, bias), 0.f);
+                Hs[rt * 16 + (lane >> 4) * 4 + i][hcol] = fmaxf(moc_fadd(pre, bias), 0.f);
             }
         W2s[threadIdx.x] = w2_pre;
     }
@@ -404,11 +404,182 @@ __global__ __launch_bounds__(256) void meta_forward64_kernel(FwdArgs a) {
             const int c = cb + ec0 + 4 * it;
             if (!erow_ok || c >= C) continue;
             float v = 0.f;   // 0 + x == x exactly, so this is the reference's running sum in both modes
-            if (a.use_bits & 1u) v = __fadd_rn(v, __fmul_rn(Gs[er][0], es0[it]));
-            if (a.use_bits & 2u) v = __fadd_rn(v, __fmul_rn(Gs[er][1], es1[it]));
-            if (a.use_bits & 4u) v = __fadd_rn(v, __fmul_rn(Gs[er][2], es2));
-            if (a.use_bits & 8u) v = __fadd_rn(v, __fmul_rn(Gs[er][3], es3));
+            if (a.use_bits & 1u) v = moc_fadd(v, moc_fmul(Gs[er][0], es0[it]));
+            if (a.use_bits & 2u) v = moc_fadd(v, moc_fmul(Gs[er][1], es1[it]));
+            if (a.use_bits & 4u) v = moc_fadd(v, moc_fmul(Gs[er][2], es2));
+            if (a.use_bits & 8u) v = moc_fadd(v, moc_fmul(Gs[er][3], es3));
             a.mixed[(int64_t)c * a.stride + base + row0 + er] = v;
+        }
+    }
+}
+
+// ---- evaluation forward, 256 rows per workgroup -----------------------------------------------------------------
+// meta_forward64_kernel still re-reads the whole 192 KiB W1 image per 64 rows: 3 KiB of image per 1 KiB of row, all of it
+// L2 -> CU traffic, and its loads, LDS stores, barrier and MFMAs run one after the other (982 us for the 2.2 M selected
+// rows of a 202-slide thirty-class evaluation: 2.3 TB/s of rows).  Here a workgroup of eight waves owns 256 rows:
+//   * the rows arrive by LDS-DMA (global_load_lds, 16 B per lane, per-lane source address = the gather through sel_row),
+//     straight into MFMA A-fragment order -- one instruction = one 16-row x 32-column fragment, 1 KiB -- in chunks of four
+//     k-steps (64 KiB), double buffered: chunk c+1 streams in while chunk c is multiplied;
+//   * wave w owns hidden units 16 (w & 3) .. +15 of rows 128 (w >> 2) .. +127: eight accumulator tiles, every W1
+//     fragment it loads feeds eight MFMAs (0.75 KiB of image per row instead of 3), the fragments of chunk c+1 requested
+//     together with its DMA, so that the only vector-memory wait of the loop is the barrier's;
+//   * A fragments are read from LDS by hand-issued ds_read_b128 in batches of four, one batch ahead of the MFMAs that
+//     use them (an ordinary LDS read would make hipcc wait vmcnt(0) first: the DMA in flight writes LDS too).
+// Same products in the same order per (row, hidden unit) as the 16- and 64-row kernels: bit-identical outputs.
+constexpr int F256_ROWS = 256, F256_KC = 4;
+constexpr int F256_BUF = (F256_ROWS / 16) * F256_KC * 1024;                  // 64 KiB: one chunk of the workgroup's rows
+constexpr int F256_LDS = (2 * F256_BUF > 256 * (H + 1) * 4 ? 2 * F256_BUF : 256 * (H + 1) * 4) + 256 * 4 * 4 + 4 * H * 4;
+typedef unsigned __attribute__((ext_vector_type(4))) fu32x4_t;
+template <int OFF>
+__device__ __forceinline__ void fwd_lds16(fu32x4_t& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void fwd_touch4(fu32x4_t (&v)[4]) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+
+template <bool F16>
+__global__ __launch_bounds__(512) void meta_forward256_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int XB = 2 * F256_BUF > 256 * (H + 1) * 4 ? 2 * F256_BUF : 256 * (H + 1) * 4;
+    float (*Hs)[H + 1] = reinterpret_cast<float (*)[H + 1]>(smem);          // [256][H + 1]: aliases the chunk buffers, after the loop
+    float (*Gs)[4] = reinterpret_cast<float (*)[4]>(smem + XB);              // [256][4]
+    float* W2s = reinterpret_cast<float*>(smem + XB + 256 * 4 * 4);          // [4][H]
+    const int b = a.slide0 + blockIdx.y;
+    const int64_t base = a.row_off[b];
+    const int S = a.n_sel[b];
+    const int row0 = blockIdx.x * F256_ROWS;
+    if (row0 >= S) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = wave >> 2, nt = wave & 3;
+    const int C = a.C;
+    const float w2_pre = a.W2[threadIdx.x & 255];
+    const float bias = a.b1[nt * 16 + (lane & 15)];
+    const float b2_pre = a.b2[threadIdx.x & 3];
+    const int64_t row_bytes = (int64_t)a.D * 2;
+    const int KK = (int)(row_bytes / 64), nchunk = KK / F256_KC;
+    // this wave fetches row tiles 2 wave, 2 wave + 1 of the workgroup: lane l = row (l & 15), 16-B piece (l >> 4) of a k-step
+    const unsigned char* rp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int sr = min(row0 + (wave * 2 + j) * 16 + (lane & 15), S - 1);
+        rp[j] = a.X + a.sel_row[base + sr] * row_bytes + (lane >> 4) * 16;
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto issue_x = [&](int c, int buf) {
+        unsigned char* dst = smem + buf * F256_BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kl = 0; kl < F256_KC; ++kl)
+                __builtin_amdgcn_global_load_lds((gptr_t)(rp[j] + ((int64_t)c * F256_KC + kl) * 64),
+                                                 (lptr_t)(dst + ((wave * 2 + j) * F256_KC + kl) * 1024), 16, 0, 0);
+    };
+    const fu32x4_t* wimg = reinterpret_cast<const fu32x4_t*>(a.W1img) + (size_t)nt * KK * 3 * 64 + lane;
+    auto load_w = [&](int c, fu32x4_t (&wv)[F256_KC * 3]) {
+#pragma unroll
+        for (int q = 0; q < F256_KC * 3; ++q) wv[q] = wimg[((size_t)c * F256_KC * 3 + q) * 64];
+    };
+    f32x4_t acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const unsigned lds0 = (unsigned)(uintptr_t)smem + lane * 16 + (half * 8) * F256_KC * 1024;
+    auto body = [&](int c, const fu32x4_t (&cur)[F256_KC * 3], fu32x4_t (&nxt)[F256_KC * 3]) {
+        if (c + 1 < nchunk) {                              // chunk c + 1: image fragments and rows, all waited for at the barrier
+            load_w(c + 1, nxt);
+            issue_x(c + 1, (c + 1) & 1);
+        }
+        const unsigned buf = lds0 + (c & 1) * F256_BUF;
+        // batches of four A fragments (row tiles 4 g .. 4 g + 3 of this half at k-step kl), one batch ahead
+        fu32x4_t A0[4], A1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fwd_lds16<0>(A0[r], buf + (r * F256_KC + 0) * 1024);
+#pragma unroll
+        for (int st = 0; st < F256_KC * 2; ++st) {         // step = (k-step kl, batch g)
+            const int kl = st >> 1, g = st & 1;
+            fu32x4_t (&Ac)[4] = (st & 1) ? A1 : A0;
+            fu32x4_t (&An)[4] = (st & 1) ? A0 : A1;
+            if (st + 1 < F256_KC * 2) {
+                const int kl_n = (st + 1) >> 1, g_n = (st + 1) & 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fwd_lds16<0>(An[r], buf + ((g_n * 4 + r) * F256_KC + kl_n) * 1024);
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            fwd_touch4(Ac);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[g * 4 + r] = moc_mfma_half<F16>(Ac[r], cur[kl * 3 + t], acc[g * 4 + r]);
+        }
+        __syncthreads();                                   // chunk c + 1 has landed for everybody; this buffer is free
+    };
+    fu32x4_t wA[F256_KC * 3], wB[F256_KC * 3];
+    load_w(0, wA);
+    issue_x(0, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; c += 2) {                  // (two chunks per trip: the fragment sets swap roles without copies)
+        body(c, wA, wB);
+        if (c + 1 < nchunk) body(c + 1, wB, wA);
+    }
+    {   // acc[r][i] = pre-activation of row half*128 + r*16 + (lane>>4)*4 + i, hidden unit nt*16 + (lane&15)
+        const int hcol = nt * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float pre = F16 ? acc[r][i] * (1.f / MOC_F16_W1_SCALE) : acc[r][i];     // exact power-of-two scaling
+                Hs[half * 128 + r * 16 + (lane >> 4) * 4 + i][hcol] = fmaxf(moc_fadd(pre, bias), 0.f);
+            }
+        if (threadIdx.x < 4 * H) W2s[threadIdx.x] = w2_pre;
+    }
+    __syncthreads();
+    if (a.H1) {                          // needed by the backward pass only: evaluation passes NULL
+        for (int e = threadIdx.x; e < F256_ROWS * H; e += 512) {
+            const int r = e >> 6, h = e & 63;
+            if (row0 + r < S) a.H1[(base + row0 + r) * H + h] = Hs[r][h];
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = (threadIdx.x >> 2) + rr * 128, i = threadIdx.x & 3;
+        float z = 0.f;
+        for (int h = 0; h < H; ++h) z = fmaf(Hs[r][h], W2s[i * H + h], z);
+        z += b2_pre;
+        const float g = 1.f / (1.f + expf(-z));
+        Gs[r][i] = g;
+        if (a.gates && row0 + r < S) a.gates[(base + row0 + r) * 4 + i] = g;
+    }
+    __syncthreads();
+    {   // the gated mix: thread -> row tid & 255, classes (tid >> 8) + 2 it; the row's operands when they are needed
+        const int er = threadIdx.x & 255, ec0 = threadIdx.x >> 8;
+        if (row0 + er < S) {
+            const float* ecd = cand_row(a, base, row0 + er);
+            float es2, es3, em1, erd;
+            cand_row_scores(a, ecd, es2, es3);
+            cand_row_norm(a, ecd, em1, erd);
+            const float g0 = Gs[er][0], g1 = Gs[er][1], g2 = Gs[er][2], g3 = Gs[er][3];
+            for (int cb = 0; cb < C; cb += 16) {
+                float es0[8], es1[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int c = cb + ec0 + 2 * it;
+                    es0[it] = es1[it] = 0.f;
+                    if (c < C) cand_class_scores(a, ecd, c, em1, erd, es0[it], es1[it]);
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int c = cb + ec0 + 2 * it;
+                    if (c >= C) continue;
+                    float v = 0.f;   // 0 + x == x exactly, so this is the reference's running sum in both modes
+                    if (a.use_bits & 1u) v = moc_fadd(v, moc_fmul(g0, es0[it]));
+                    if (a.use_bits & 2u) v = moc_fadd(v, moc_fmul(g1, es1[it]));
+                    if (a.use_bits & 4u) v = moc_fadd(v, moc_fmul(g2, es2));
+                    if (a.use_bits & 8u) v = moc_fadd(v, moc_fmul(g3, es3));
+                    a.mixed[(int64_t)c * a.stride + base + row0 + er] = v;
+                }
+            }
         }
     }
 }
@@ -425,8 +596,8 @@ __global__ __launch_bounds__(256) void fixed_mix_kernel(FwdArgs a, int mode) {
     for (int c = 0; c < C; ++c) {
         const float s0 = cd[(int64_t)c * a.stride], s1 = cd[(int64_t)(C + c) * a.stride];
         float v;
-        if (mode == 0) v = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(0.25f, s0), __fmul_rn(0.25f, s1)), __fmul_rn(0.25f, s2)), __fmul_rn(0.25f, s3));
-        else if (mode == 1) v = __fadd_rn(__fadd_rn(__fadd_rn(s0, s1), s2), s3);
+        if (mode == 0) v = moc_fadd(moc_fadd(moc_fadd(moc_fmul(0.25f, s0), moc_fmul(0.25f, s1)), moc_fmul(0.25f, s2)), moc_fmul(0.25f, s3));
+        else if (mode == 1) v = moc_fadd(moc_fadd(moc_fadd(s0, s1), s2), s3);
         else v = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
         a.mixed[(int64_t)c * a.stride + base + s] = v;
     }
@@ -1589,6 +1760,22 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
         a.stats = B->stats; a.sel_idx = B->sel_idx;
     }
     dim3 grid(moc_cdiv(s_bound(B), 16), n);
+    static const int fwd_variant = getenv("MOC_FORWARD_EVAL") ? atoi(getenv("MOC_FORWARD_EVAL")) : 256;   // diagnostic: 64 = the 64-row kernel
+    if (n >= 4 && B->dtype != MOC_F32 && (B->D * 2) % 512 == 0 && s_bound(B) >= 1024 && fwd_variant == 256 &&
+        !(B->flags & MOC_FORWARD_ROWS64)) {
+        // many slides of many selected rows (evaluation): 256 rows per workgroup, rows by LDS-DMA
+        static bool attr256 = false;
+        if (!attr256) {
+            (void)hipFuncSetAttribute((const void*)meta_forward256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F256_LDS);
+            (void)hipFuncSetAttribute((const void*)meta_forward256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F256_LDS);
+            attr256 = true;
+        }
+        dim3 g256(moc_cdiv(s_bound(B), F256_ROWS), n);
+        if (B->dtype == MOC_F16) meta_forward256_kernel<true><<<g256, 512, F256_LDS, s>>>(a);
+        else meta_forward256_kernel<false><<<g256, 512, F256_LDS, s>>>(a);
+        MOC_CHECK_LAUNCH("moc_meta_forward(256)");
+        return MOC_OK;
+    }
     if (n >= 4 && B->dtype != MOC_F32 && (B->D * 2) % 512 == 0) {       // many slides at once (evaluation)
         dim3 g64(moc_cdiv(s_bound(B), 64), n);
         if (B->dtype == MOC_F16) meta_forward64_kernel<true><<<g64, 256, 0, s>>>(a);

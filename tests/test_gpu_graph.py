@@ -106,9 +106,17 @@ def test_graph_survives_table_rebuilds_and_foreign_steps(gpu_device):
 
 def test_graph_matches_oracle_losses(gpu_device):
     """The graph path against the CPU oracle directly (not only against the stream launches)."""
-    from moc_amd import main_moc as M
+    from moc_amd import engine as E, main_moc as M
     from oracle import moc_oracle as O
     dev = gpu_device
+    keep, E.STEP_GRAPH = E.STEP_GRAPH, True             # (opt-in: stream launches are the default, MOC_STEP_GRAPH=1 switches)
+    try:
+        _graph_vs_oracle(dev, E, M, O)
+    finally:
+        E.STEP_GRAPH = keep
+
+
+def _graph_vs_oracle(dev, E, M, O):
     C, j, K = 2, 100, 10
     W, We = synth.make_bank(9, 512, C)
     bags, labels = synth.make_slide_set(900, [1000, 1200, 900, 1100], 512, We, C)
@@ -128,7 +136,6 @@ def test_graph_matches_oracle_losses(gpu_device):
         res.next_pass_len = 0
         M.train(model, res, opt, dev, args)
         np.testing.assert_allclose(M.train.last[0].meta_ws()[0]["loss"].cpu().numpy(), np.asarray(ref_losses), atol=H.ATOL)
-    from moc_amd import engine as E
     assert E.MetaState.cached(model, opt).graph_stats()[1] == 3
     H.assert_adam_params_close(H.flat_params(model), H.flat_params(ref_model), H.flat_state(ref_opt, "exp_avg_sq"),
                                step=12, grad_noise=1e-6, what="graph path, 3 epochs")

@@ -612,21 +612,27 @@ def test_full_size_properties(dev):
     assert abs(ev["loss"] - ev_ref["loss"]) < ATOL and ev["acc"] == ev_ref["acc"] and abs(ev["auc"] - ev_ref["auc"]) < 2e-3
 
 
-@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 512), (torch.float16, 512), (torch.bfloat16, 768), (torch.float16, 256)])
-def test_batched_forward_is_bit_identical_to_one_slide_at_a_time(dev, dtype, D):
-    """Many slides at once take the 64-row forward kernel (W1 fragments shared by four row tiles); the
-    meta-step's one-slide kernel must give the same bits: hidden layer, gates and mixed scores."""
+@pytest.mark.parametrize("rows64", [False, True])
+@pytest.mark.parametrize("dtype,D,C", [(torch.bfloat16, 512, 3), (torch.float16, 512, 3), (torch.bfloat16, 768, 3), (torch.float16, 256, 3),
+                                       (torch.bfloat16, 512, 30), (torch.bfloat16, 1024, 20)])
+def test_batched_forward_is_bit_identical_to_one_slide_at_a_time(dev, dtype, D, C, rows64):
+    """Many slides at once take the 256-row forward kernel (rows by LDS-DMA, W1 fragments shared by eight row tiles) or,
+    with MOC_FORWARD_ROWS64 / fewer selectable rows, the 64-row one (fragments shared by four); the meta-step's one-slide
+    kernel must give the same bits: hidden layer, gates and mixed scores."""
     M, E = _mm(), _engine()
-    C, j, K = 3, 150, 10
+    from moc_amd import _lib
+    j, K = 150, 10
     W, We = synth.make_bank(71, D, C)
     Wd, Wed = W.to(dev), We.to(dev)
-    sizes = [900, 1500, 64, 2100, 333, 1207]
+    sizes = [900, 1500, 64, 2100, 333, 1207, 2600]
     bags = [synth.make_bag_device(7100 + i, n, D, We, C, i % C, dev, dtype) for i, n in enumerate(sizes)]
     torch.manual_seed(3)
     model = M.senet(D, 4).to(dev)
     X, _ = M._pack(bags, dev, dtype)
     b = E.SlideBatch(X, sizes, C, C + 4, j, K)
+    b.c.flags = _lib.MOC_FORWARD_ROWS64 if rows64 else 0
     b.phase_a(E.Bank.get(Wd, Wed, dtype, dev))
+    assert bool(b.c.flags & _lib.MOC_FORWARD_ROWS64) == rows64
     meta = E.MetaState(model)
     t = b.meta_ws()[0]
     E.meta_forward(b, meta, 0, len(sizes), 15)
