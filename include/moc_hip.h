@@ -62,7 +62,7 @@ enum { MOC_STATS_COMPACT = 1,
         * moc_mix_fixed, moc_pack_selected*) refuse such a batch. */
        MOC_CAND_FROM_STATS = 4,
        /* moc_meta_forward over many slides: keep to 64 rows per workgroup (the default for launches of at least four
-        * slides with 1024 or more selectable rows on 16-bit bags is 256 rows per workgroup, rows by LDS-DMA); both give
+        * slides with 1024 or more selectable rows on 16-bit bags is 128 rows per workgroup, rows by LDS-DMA); both give
         * the bits of the one-slide kernel -- the bit exists so that tests can say so */
        MOC_FORWARD_ROWS64 = 8 };
 

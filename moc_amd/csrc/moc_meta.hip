@@ -413,22 +413,30 @@ __global__ __launch_bounds__(256) void meta_forward64_kernel(FwdArgs a) {
     }
 }
 
-// ---- evaluation forward, 256 rows per workgroup -----------------------------------------------------------------
-// meta_forward64_kernel still re-reads the whole 192 KiB W1 image per 64 rows: 3 KiB of image per 1 KiB of row, all of it
-// L2 -> CU traffic, and its loads, LDS stores, barrier and MFMAs run one after the other (982 us for the 2.2 M selected
-// rows of a 202-slide thirty-class evaluation: 2.3 TB/s of rows).  Here a workgroup of eight waves owns 256 rows:
+// ---- evaluation forward, 128 rows per workgroup, rows by LDS-DMA -------------------------------------------------
+// meta_forward64_kernel re-reads the whole 192 KiB W1 image per 64 rows (3 KiB of image per 1 KiB of row, all of it L2 -> CU
+// traffic), its loads, LDS stores, barrier and MFMAs run one after the other, and its mix waits for operands it asks for
+// late: 1,000-1,070 us for the 2.0 M selected rows of a 202-slide thirty-class evaluation (1.9 TB/s of rows).  Peeling
+// (scripts/bench_forward.py on a first, 256-row form of this kernel: 1,068 us whole, 724 without the mix, 336 with
+// nothing but its skeleton) showed where the time is: NOT in the product (340 us of the 1,068) but in what a workgroup
+// does alone on its CU before and after it -- the dependent first touches of its prologue and the mix's three round
+// trips, 7 us per workgroup with nothing to hide them behind.  So:
+//   * 128 rows per workgroup of four waves and 70 KiB of LDS: TWO workgroups per CU, one's prologue and epilogue beside
+//     the other's product;
 //   * the rows arrive by LDS-DMA (global_load_lds, 16 B per lane, per-lane source address = the gather through sel_row),
 //     straight into MFMA A-fragment order -- one instruction = one 16-row x 32-column fragment, 1 KiB -- in chunks of four
-//     k-steps (64 KiB), double buffered: chunk c+1 streams in while chunk c is multiplied;
-//   * wave w owns hidden units 16 (w & 3) .. +15 of rows 128 (w >> 2) .. +127: eight accumulator tiles, every W1
-//     fragment it loads feeds eight MFMAs (0.75 KiB of image per row instead of 3), the fragments of chunk c+1 requested
-//     together with its DMA, so that the only vector-memory wait of the loop is the barrier's;
+//     k-steps (32 KiB), double buffered: chunk c+1 streams in while chunk c is multiplied;
+//   * wave w owns hidden units 16 w .. +15 of all 128 rows: eight accumulator tiles, every W1 fragment it loads feeds
+//     eight MFMAs (1.5 KiB of image per row instead of 3), the fragments of chunk c+1 requested together with its DMA,
+//     so that the only vector-memory wait of the loop is the barrier's;
 //   * A fragments are read from LDS by hand-issued ds_read_b128 in batches of four, one batch ahead of the MFMAs that
-//     use them (an ordinary LDS read would make hipcc wait vmcnt(0) first: the DMA in flight writes LDS too).
+//     use them (an ordinary LDS read would make hipcc wait vmcnt(0) first: the DMA in flight writes LDS too);
+//   * the mix's operands (the row's candidate scores, the first 16 classes) are requested at kernel start, consumed last.
 // Same products in the same order per (row, hidden unit) as the 16- and 64-row kernels: bit-identical outputs.
-constexpr int F256_ROWS = 256, F256_KC = 4;
-constexpr int F256_BUF = (F256_ROWS / 16) * F256_KC * 1024;                  // 64 KiB: one chunk of the workgroup's rows
-constexpr int F256_LDS = (2 * F256_BUF > 256 * (H + 1) * 4 ? 2 * F256_BUF : 256 * (H + 1) * 4) + 256 * 4 * 4 + 4 * H * 4;
+constexpr int F128_ROWS = 128, F128_KC = 4;
+constexpr int F128_BUF = (F128_ROWS / 16) * F128_KC * 1024;                  // 32 KiB: one chunk of the workgroup's rows
+constexpr int F128_XB = 2 * F128_BUF > F128_ROWS * (H + 1) * 4 ? 2 * F128_BUF : F128_ROWS * (H + 1) * 4;
+constexpr int F128_LDS = F128_XB + F128_ROWS * 4 * 4 + 4 * H * 4;            // + gates + W2: 68.6 KiB, two workgroups per CU
 typedef unsigned __attribute__((ext_vector_type(4))) fu32x4_t;
 template <int OFF>
 __device__ __forceinline__ void fwd_lds16(fu32x4_t& dst, unsigned addr) {
@@ -439,24 +447,45 @@ __device__ __forceinline__ void fwd_touch4(fu32x4_t (&v)[4]) {
 }
 
 template <bool F16>
-__global__ __launch_bounds__(512) void meta_forward256_kernel(FwdArgs a) {
+__global__ __launch_bounds__(256, 2) void meta_forward128_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int XB = 2 * F256_BUF > 256 * (H + 1) * 4 ? 2 * F256_BUF : 256 * (H + 1) * 4;
-    float (*Hs)[H + 1] = reinterpret_cast<float (*)[H + 1]>(smem);          // [256][H + 1]: aliases the chunk buffers, after the loop
-    float (*Gs)[4] = reinterpret_cast<float (*)[4]>(smem + XB);              // [256][4]
-    float* W2s = reinterpret_cast<float*>(smem + XB + 256 * 4 * 4);          // [4][H]
+    float (*Hs)[H + 1] = reinterpret_cast<float (*)[H + 1]>(smem);          // [128][H + 1]: aliases the chunk buffers, after the loop
+    float (*Gs)[4] = reinterpret_cast<float (*)[4]>(smem + F128_XB);         // [128][4]
+    float* W2s = reinterpret_cast<float*>(smem + F128_XB + F128_ROWS * 4 * 4);      // [4][H]
     const int b = a.slide0 + blockIdx.y;
     const int64_t base = a.row_off[b];
     const int S = a.n_sel[b];
-    const int row0 = blockIdx.x * F256_ROWS;
+    const int row0 = blockIdx.x * F128_ROWS;
     if (row0 >= S) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = wave >> 2, nt = wave & 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = a.C;
+#ifdef MOC_FWD_DIAG
+    const unsigned diag = a.use_bits >> 8;                 // peeling experiments (scripts/bench_forward.py): 1 no MFMA, 2 no W1 loads, 4 no row DMA, 8 no mix
+#else
+    constexpr unsigned diag = 0;
+#endif
+    // ---- the mix's operands: thread -> row tid & 127, classes (tid >> 7) + 2 it.  Requested now, consumed at the end.
+    const int er = threadIdx.x & 127, ec0 = threadIdx.x >> 7;
+    const bool erow_ok = row0 + er < S;
+    const float* ecd = cand_row(a, base, erow_ok ? row0 + er : row0);
+    // (s_p only: s_sigma is re-formed from it with the compact statistics, and loaded at the end otherwise -- the
+    // registers of a second array are what the product needs)
+    float es2 = 0.f, es3 = 0.f, em1 = 0.f, erd = 0.f, es0[8];
+    if (erow_ok) {
+        cand_row_scores(a, ecd, es2, es3);
+        cand_row_norm(a, ecd, em1, erd);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int c = ec0 + 2 * it;
+        es0[it] = 0.f;
+        if (erow_ok && c < C) es0[it] = ecd[(int64_t)c * a.stride];
+    }
     const float w2_pre = a.W2[threadIdx.x & 255];
-    const float bias = a.b1[nt * 16 + (lane & 15)];
+    const float bias = a.b1[wave * 16 + (lane & 15)];
     const float b2_pre = a.b2[threadIdx.x & 3];
     const int64_t row_bytes = (int64_t)a.D * 2;
-    const int KK = (int)(row_bytes / 64), nchunk = KK / F256_KC;
+    const int KK = (int)(row_bytes / 64), nchunk = KK / F128_KC;
     // this wave fetches row tiles 2 wave, 2 wave + 1 of the workgroup: lane l = row (l & 15), 16-B piece (l >> 4) of a k-step
     const unsigned char* rp[2];
 #pragma unroll
@@ -467,55 +496,57 @@ __global__ __launch_bounds__(512) void meta_forward256_kernel(FwdArgs a) {
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     auto issue_x = [&](int c, int buf) {
-        unsigned char* dst = smem + buf * F256_BUF;
+        unsigned char* dst = smem + buf * F128_BUF;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int kl = 0; kl < F256_KC; ++kl)
-                __builtin_amdgcn_global_load_lds((gptr_t)(rp[j] + ((int64_t)c * F256_KC + kl) * 64),
-                                                 (lptr_t)(dst + ((wave * 2 + j) * F256_KC + kl) * 1024), 16, 0, 0);
+            for (int kl = 0; kl < F128_KC; ++kl)
+                __builtin_amdgcn_global_load_lds((gptr_t)(rp[j] + ((int64_t)c * F128_KC + kl) * 64),
+                                                 (lptr_t)(dst + ((wave * 2 + j) * F128_KC + kl) * 1024), 16, 0, 0);
     };
-    const fu32x4_t* wimg = reinterpret_cast<const fu32x4_t*>(a.W1img) + (size_t)nt * KK * 3 * 64 + lane;
-    auto load_w = [&](int c, fu32x4_t (&wv)[F256_KC * 3]) {
+    const fu32x4_t* wimg = reinterpret_cast<const fu32x4_t*>(a.W1img) + (size_t)wave * KK * 3 * 64 + lane;
+    auto load_w = [&](int c, fu32x4_t (&wv)[F128_KC * 3]) {
 #pragma unroll
-        for (int q = 0; q < F256_KC * 3; ++q) wv[q] = wimg[((size_t)c * F256_KC * 3 + q) * 64];
+        for (int q = 0; q < F128_KC * 3; ++q) wv[q] = wimg[((size_t)c * F128_KC * 3 + q) * 64];
     };
     f32x4_t acc[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const unsigned lds0 = (unsigned)(uintptr_t)smem + lane * 16 + (half * 8) * F256_KC * 1024;
-    auto body = [&](int c, const fu32x4_t (&cur)[F256_KC * 3], fu32x4_t (&nxt)[F256_KC * 3]) {
+    const unsigned lds0 = (unsigned)(uintptr_t)smem + lane * 16;
+    auto body = [&](int c, const fu32x4_t (&cur)[F128_KC * 3], fu32x4_t (&nxt)[F128_KC * 3]) {
         if (c + 1 < nchunk) {                              // chunk c + 1: image fragments and rows, all waited for at the barrier
-            load_w(c + 1, nxt);
-            issue_x(c + 1, (c + 1) & 1);
+            if (!(diag & 2u)) load_w(c + 1, nxt);
+            if (!(diag & 4u)) issue_x(c + 1, (c + 1) & 1);
         }
-        const unsigned buf = lds0 + (c & 1) * F256_BUF;
-        // batches of four A fragments (row tiles 4 g .. 4 g + 3 of this half at k-step kl), one batch ahead
-        fu32x4_t A0[4], A1[4];
+        const unsigned buf = lds0 + (c & 1) * F128_BUF;
+        // batches of two A fragments (row tiles 2 g, 2 g + 1 at k-step kl), one batch ahead of the six MFMAs that use them
+        fu32x4_t A0[2], A1[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) fwd_lds16<0>(A0[r], buf + (r * F256_KC + 0) * 1024);
+        for (int r = 0; r < 2; ++r) fwd_lds16<0>(A0[r], buf + (r * F128_KC + 0) * 1024);
 #pragma unroll
-        for (int st = 0; st < F256_KC * 2; ++st) {         // step = (k-step kl, batch g)
-            const int kl = st >> 1, g = st & 1;
-            fu32x4_t (&Ac)[4] = (st & 1) ? A1 : A0;
-            fu32x4_t (&An)[4] = (st & 1) ? A0 : A1;
-            if (st + 1 < F256_KC * 2) {
-                const int kl_n = (st + 1) >> 1, g_n = (st + 1) & 1;
+        for (int st = 0; st < F128_KC * 4; ++st) {         // step = (k-step kl, batch g)
+            const int kl = st >> 2, g = st & 3;
+            fu32x4_t (&Ac)[2] = (st & 1) ? A1 : A0;
+            fu32x4_t (&An)[2] = (st & 1) ? A0 : A1;
+            if (st + 1 < F128_KC * 4) {
+                const int kl_n = (st + 1) >> 2, g_n = (st + 1) & 3;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) fwd_lds16<0>(An[r], buf + ((g_n * 4 + r) * F256_KC + kl_n) * 1024);
-                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                for (int r = 0; r < 2; ++r) fwd_lds16<0>(An[r], buf + ((g_n * 2 + r) * F128_KC + kl_n) * 1024);
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            fwd_touch4(Ac);
+            asm volatile("" : "+v"(Ac[0]), "+v"(Ac[1]));
+            if (!(diag & 1u)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) acc[g * 4 + r] = moc_mfma_half<F16>(Ac[r], cur[kl * 3 + t], acc[g * 4 + r]);
+                    for (int t = 0; t < 3; ++t) acc[g * 2 + r] = moc_mfma_half<F16>(Ac[r], cur[kl * 3 + t], acc[g * 2 + r]);
+            }
         }
         __syncthreads();                                   // chunk c + 1 has landed for everybody; this buffer is free
     };
-    fu32x4_t wA[F256_KC * 3], wB[F256_KC * 3];
+    fu32x4_t wA[F128_KC * 3], wB[F128_KC * 3];
     load_w(0, wA);
     issue_x(0, 0);
     __syncthreads();
@@ -523,27 +554,27 @@ __global__ __launch_bounds__(512) void meta_forward256_kernel(FwdArgs a) {
         body(c, wA, wB);
         if (c + 1 < nchunk) body(c + 1, wB, wA);
     }
-    {   // acc[r][i] = pre-activation of row half*128 + r*16 + (lane>>4)*4 + i, hidden unit nt*16 + (lane&15)
-        const int hcol = nt * 16 + (lane & 15);
+    {   // acc[r][i] = pre-activation of row r*16 + (lane>>4)*4 + i, hidden unit wave*16 + (lane&15)
+        const int hcol = wave * 16 + (lane & 15);
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float pre = F16 ? acc[r][i] * (1.f / MOC_F16_W1_SCALE) : acc[r][i];     // exact power-of-two scaling
-                Hs[half * 128 + r * 16 + (lane >> 4) * 4 + i][hcol] = fmaxf(moc_fadd(pre, bias), 0.f);
+                Hs[r * 16 + (lane >> 4) * 4 + i][hcol] = fmaxf(moc_fadd(pre, bias), 0.f);
             }
-        if (threadIdx.x < 4 * H) W2s[threadIdx.x] = w2_pre;
+        W2s[threadIdx.x] = w2_pre;
     }
     __syncthreads();
     if (a.H1) {                          // needed by the backward pass only: evaluation passes NULL
-        for (int e = threadIdx.x; e < F256_ROWS * H; e += 512) {
+        for (int e = threadIdx.x; e < F128_ROWS * H; e += 256) {
             const int r = e >> 6, h = e & 63;
             if (row0 + r < S) a.H1[(base + row0 + r) * H + h] = Hs[r][h];
         }
     }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-        const int r = (threadIdx.x >> 2) + rr * 128, i = threadIdx.x & 3;
+        const int r = (threadIdx.x >> 2) + rr * 64, i = threadIdx.x & 3;
         float z = 0.f;
         for (int h = 0; h < H; ++h) z = fmaf(Hs[r][h], W2s[i * H + h], z);
         z += b2_pre;
@@ -552,33 +583,34 @@ __global__ __launch_bounds__(512) void meta_forward256_kernel(FwdArgs a) {
         if (a.gates && row0 + r < S) a.gates[(base + row0 + r) * 4 + i] = g;
     }
     __syncthreads();
-    {   // the gated mix: thread -> row tid & 255, classes (tid >> 8) + 2 it; the row's operands when they are needed
-        const int er = threadIdx.x & 255, ec0 = threadIdx.x >> 8;
-        if (row0 + er < S) {
-            const float* ecd = cand_row(a, base, row0 + er);
-            float es2, es3, em1, erd;
-            cand_row_scores(a, ecd, es2, es3);
-            cand_row_norm(a, ecd, em1, erd);
-            const float g0 = Gs[er][0], g1 = Gs[er][1], g2 = Gs[er][2], g3 = Gs[er][3];
-            for (int cb = 0; cb < C; cb += 16) {
-                float es0[8], es1[8];
+    if (erow_ok && !(diag & 8u)) {
+        const float g0 = Gs[er][0], g1 = Gs[er][1], g2 = Gs[er][2], g3 = Gs[er][3];
+        for (int cb = 0; cb < C; cb += 16) {
+            if (cb > 0) {                                  // beyond the 16 classes requested at the start
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int c = cb + ec0 + 2 * it;
-                    es0[it] = es1[it] = 0.f;
-                    if (c < C) cand_class_scores(a, ecd, c, em1, erd, es0[it], es1[it]);
+                    if (c < C) es0[it] = ecd[(int64_t)c * a.stride];
                 }
+            }
+            float es1[8];
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int c = cb + ec0 + 2 * it;
-                    if (c >= C) continue;
-                    float v = 0.f;   // 0 + x == x exactly, so this is the reference's running sum in both modes
-                    if (a.use_bits & 1u) v = moc_fadd(v, moc_fmul(g0, es0[it]));
-                    if (a.use_bits & 2u) v = moc_fadd(v, moc_fmul(g1, es1[it]));
-                    if (a.use_bits & 4u) v = moc_fadd(v, moc_fmul(g2, es2));
-                    if (a.use_bits & 8u) v = moc_fadd(v, moc_fmul(g3, es3));
-                    a.mixed[(int64_t)c * a.stride + base + row0 + er] = v;
-                }
+            for (int it = 0; it < 8; ++it) {
+                const int c = cb + ec0 + 2 * it;
+                es1[it] = 0.f;
+                if (c < C) es1[it] = a.cand_mode == 2 ? moc_softmax_from(es0[it], em1, erd) : ecd[(int64_t)(C + c) * a.stride];
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int c = cb + ec0 + 2 * it;
+                if (c >= C) continue;
+                const float s1 = es1[it];
+                float v = 0.f;   // 0 + x == x exactly, so this is the reference's running sum in both modes
+                if (a.use_bits & 1u) v = moc_fadd(v, moc_fmul(g0, es0[it]));
+                if (a.use_bits & 2u) v = moc_fadd(v, moc_fmul(g1, s1));
+                if (a.use_bits & 4u) v = moc_fadd(v, moc_fmul(g2, es2));
+                if (a.use_bits & 8u) v = moc_fadd(v, moc_fmul(g3, es3));
+                a.mixed[(int64_t)c * a.stride + base + row0 + er] = v;
             }
         }
     }
@@ -1752,6 +1784,9 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
     a.W1img = (const unsigned char*)M->W1_image;
     a.H1 = ws->H1; a.gates = ws->gates; a.mixed = ws->mixed; a.stride = B->total_rows;
     a.D = B->D; a.C = B->C; a.slide0 = slide0; a.use_bits = use_bits;
+#ifdef MOC_FWD_DIAG
+    if (const char* dg = getenv("MOC_FWD_DIAG")) a.use_bits |= (uint32_t)atoi(dg) << 8;
+#endif
     a.base_host = (n == 1 && B->row_off_host) ? B->row_off_host[slide0] : -1;
     a.cand_mode = 0; a.stats = nullptr; a.sel_idx = nullptr;
     if (B->flags & MOC_CAND_FROM_STATS) {
@@ -1760,20 +1795,20 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
         a.stats = B->stats; a.sel_idx = B->sel_idx;
     }
     dim3 grid(moc_cdiv(s_bound(B), 16), n);
-    static const int fwd_variant = getenv("MOC_FORWARD_EVAL") ? atoi(getenv("MOC_FORWARD_EVAL")) : 256;   // diagnostic: 64 = the 64-row kernel
-    if (n >= 4 && B->dtype != MOC_F32 && (B->D * 2) % 512 == 0 && s_bound(B) >= 1024 && fwd_variant == 256 &&
+    static const int fwd_variant = getenv("MOC_FORWARD_EVAL") ? atoi(getenv("MOC_FORWARD_EVAL")) : 128;   // diagnostic: 64 = the 64-row kernel
+    if (n >= 4 && B->dtype != MOC_F32 && (B->D * 2) % 512 == 0 && s_bound(B) >= 1024 && fwd_variant == 128 &&
         !(B->flags & MOC_FORWARD_ROWS64)) {
-        // many slides of many selected rows (evaluation): 256 rows per workgroup, rows by LDS-DMA
-        static bool attr256 = false;
-        if (!attr256) {
-            (void)hipFuncSetAttribute((const void*)meta_forward256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F256_LDS);
-            (void)hipFuncSetAttribute((const void*)meta_forward256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F256_LDS);
-            attr256 = true;
+        // many slides of many selected rows (evaluation): 128 rows per workgroup, rows by LDS-DMA, two workgroups per CU
+        static bool attr128 = false;
+        if (!attr128) {
+            (void)hipFuncSetAttribute((const void*)meta_forward128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F128_LDS);
+            (void)hipFuncSetAttribute((const void*)meta_forward128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F128_LDS);
+            attr128 = true;
         }
-        dim3 g256(moc_cdiv(s_bound(B), F256_ROWS), n);
-        if (B->dtype == MOC_F16) meta_forward256_kernel<true><<<g256, 512, F256_LDS, s>>>(a);
-        else meta_forward256_kernel<false><<<g256, 512, F256_LDS, s>>>(a);
-        MOC_CHECK_LAUNCH("moc_meta_forward(256)");
+        dim3 g128(moc_cdiv(s_bound(B), F128_ROWS), n);
+        if (B->dtype == MOC_F16) meta_forward128_kernel<true><<<g128, 256, F128_LDS, s>>>(a);
+        else meta_forward128_kernel<false><<<g128, 256, F128_LDS, s>>>(a);
+        MOC_CHECK_LAUNCH("moc_meta_forward(128)");
         return MOC_OK;
     }
     if (n >= 4 && B->dtype != MOC_F32 && (B->D * 2) % 512 == 0) {       // many slides at once (evaluation)
