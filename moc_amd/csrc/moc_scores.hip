@@ -191,7 +191,8 @@ __device__ __forceinline__ void xor_pair(float x, float& lo, float& hi) {
 // top-2 by min / max, the cross-lane merges by row swaps, exp as v_exp_f32 of (v - max) log2(e) -- exactly 1 at the
 // maximum, relative error 2e-7 elsewhere, no denormal tail -- and ONE division per row (p = e * (1 / den)).
 template <int Q>
-__device__ __forceinline__ void row_stats_emit(const ScoresArgs& a, const float (&v)[Q], int64_t slot_base, int row0, int nk) {
+__device__ __forceinline__ void row_stats_emit(const ScoresArgs& a, const float (&v)[Q], int64_t slot_base, int row0, int nk,
+                                               const float* tile, int ldt) {
     const int lane = threadIdx.x & 63, row = lane & 15, part = lane >> 4;
     const int C = a.C, Ce = a.Ce;
     const int qc = (C - part + 3) >> 2, qe = (Ce - part + 3) >> 2;          // c = 4 q + part < C  <=>  q < qc
@@ -228,7 +229,8 @@ __device__ __forceinline__ void row_stats_emit(const ScoresArgs& a, const float 
         xor_pair<16>(den, d0, d1); den = d0 + d1;
         xor_pair<32>(den, d0, d1); den = d0 + d1;
     }
-    if ((unsigned)(row0 + row) >= (unsigned)nk) return;          // beyond the slide (or, in a short first tile, before it)
+    const bool own_row = (unsigned)(row0 + row) < (unsigned)nk;  // else: beyond the slide (or, in a short first tile, before it)
+    if (!own_row && !a.compact) return;                          // (the compact form's 16-byte stores use another lane mapping)
 #ifdef MOC_STAMPS
     if (a.tpw == 7) {                                  // diagnostic (MOC_EPI_MODE=7): everything computed, nothing stored
 #pragma unroll
@@ -246,16 +248,40 @@ __device__ __forceinline__ void row_stats_emit(const ScoresArgs& a, const float 
     if (a.compact) {
         // C + 5 columns: the logits, then m1 | 1/den | gap | bg_sum | bg_max.  The softmax columns are what the selector
         // and the candidate gather re-form from (v, m1, 1/den) with exactly the arithmetic above: e * rden.
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            if (q < qc) sv[off] = v[q];
-            sv += 4 * stride;
+        if (own_row) {
+            float* st = a.stats + slot_base + (int64_t)C * stride + (row0 + row);
+            if (part == 0) { st[0] = m1; st[2 * stride] = fabsf(m1 - m2); }
+            else if (part == 1) { st[stride] = rden; st[3 * stride] = bsum; }
+            else if (part == 2) st[4 * stride] = bmax;
+            else a.sel_flag[slot_base + row0 + row] = 0;
         }
-        float* st = a.stats + slot_base + (int64_t)C * stride + (row0 + row);
-        if (part == 0) { st[0] = m1; st[2 * stride] = fabsf(m1 - m2); }
-        else if (part == 1) { st[stride] = rden; st[3 * stride] = bsum; }
-        else if (part == 2) st[4 * stride] = bmax;
-        else a.sel_flag[slot_base + row0 + row] = 0;
+        // The logits leave as 16-byte stores: lane -> column 16 p + (lane >> 2), rows 4 (lane & 3) .. + 3 of the tile, read
+        // back from the wave's LDS tile (where they are the v[] above).  One store instruction carries 16 columns x 64 B
+        // instead of 4: the tile's C columns take ceil(C / 16) instructions, not ceil(C / 4) -- the wave was held by its
+        // store issue (round 2: 2,000 of a tile's 8,000 cycles at thirty classes).  Tiles are cut at absolute multiples
+        // of 16 slots, so a whole quad is 16-byte aligned; quads that straddle the slide's ends go row by row.
+        const int rg = lane & 3, cq = lane >> 2;
+        const int r_lo = row0 + rg * 4;
+        const bool whole = r_lo >= 0 && r_lo + 3 < nk;
+        for (int c0 = 0; c0 < C; c0 += 16) {
+            const int c = c0 + cq;
+            if (c >= C) continue;
+            const float* tp = tile + (rg * 4) * ldt + c;
+            const float x0 = tp[0], x1 = tp[ldt], x2 = tp[2 * ldt], x3 = tp[3 * ldt];
+            float* dst = a.stats + slot_base + (int64_t)c * stride + r_lo;
+            if (whole) {
+                // (4-byte aligned in general -- a column starts at c * total_rows floats -- and 16-byte aligned whenever the
+                // batch's total is a multiple of four: global_store_dwordx4 takes either)
+                typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));
+                f32x4u_t pk = {x0, x1, x2, x3};
+                *reinterpret_cast<f32x4u_t*>(dst) = pk;
+            } else {
+                if ((unsigned)(r_lo + 0) < (unsigned)nk) dst[0] = x0;
+                if ((unsigned)(r_lo + 1) < (unsigned)nk) dst[1] = x1;
+                if ((unsigned)(r_lo + 2) < (unsigned)nk) dst[2] = x2;
+                if ((unsigned)(r_lo + 3) < (unsigned)nk) dst[3] = x3;
+            }
+        }
         return;
     }
 #pragma unroll
@@ -284,7 +310,7 @@ __device__ __forceinline__ void row_epilogue_wide(const ScoresArgs& a, const flo
     float v[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) v[q] = tile[row * LDT + q * 4 + part];
-    row_stats_emit<Q>(a, v, slot_base, row0, nk);
+    row_stats_emit<Q>(a, v, slot_base, row0, nk, tile, LDT);
 }
 
 // CH = elements of K held in registers per chunk (512 or 256).  BF16: bf16 bag.
