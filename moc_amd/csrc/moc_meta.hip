@@ -446,8 +446,13 @@ __device__ __forceinline__ void fwd_touch4(fu32x4_t (&v)[4]) {
     asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
 }
 
-template <bool F16>
+// ST: storage of the bag -- 0 bf16, 1 fp16 (three 16-bit terms of W1 per k-step of 32 columns, v_mfma_f32_16x16x32),
+// 2 fp32 (one fp32 fragment per k-step of 16 columns, four v_mfma_f32_16x16x4_f32)
+template <int ST>
 __global__ __launch_bounds__(256, 2) void meta_forward128_kernel(FwdArgs a) {
+    constexpr bool F16 = ST == 1;
+    constexpr int PER = ST == 2 ? 1 : 3;                   // W1 fragments per k-step
+    constexpr int ESZ = ST == 2 ? 4 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float (*Hs)[H + 1] = reinterpret_cast<float (*)[H + 1]>(smem);          // [128][H + 1]: aliases the chunk buffers, after the loop
     float (*Gs)[4] = reinterpret_cast<float (*)[4]>(smem + F128_XB);         // [128][4]
@@ -484,8 +489,8 @@ __global__ __launch_bounds__(256, 2) void meta_forward128_kernel(FwdArgs a) {
     const float w2_pre = a.W2[threadIdx.x & 255];
     const float bias = a.b1[wave * 16 + (lane & 15)];
     const float b2_pre = a.b2[threadIdx.x & 3];
-    const int64_t row_bytes = (int64_t)a.D * 2;
-    const int KK = (int)(row_bytes / 64), nchunk = KK / F128_KC;
+    const int64_t row_bytes = (int64_t)a.D * ESZ;
+    const int KK = (int)(row_bytes / 64), nchunk = KK / F128_KC;      // k-steps of 64 bytes of a row
     // this wave fetches row tiles 2 wave, 2 wave + 1 of the workgroup: lane l = row (l & 15), 16-B piece (l >> 4) of a k-step
     const unsigned char* rp[2];
 #pragma unroll
@@ -504,16 +509,16 @@ __global__ __launch_bounds__(256, 2) void meta_forward128_kernel(FwdArgs a) {
                 __builtin_amdgcn_global_load_lds((gptr_t)(rp[j] + ((int64_t)c * F128_KC + kl) * 64),
                                                  (lptr_t)(dst + ((wave * 2 + j) * F128_KC + kl) * 1024), 16, 0, 0);
     };
-    const fu32x4_t* wimg = reinterpret_cast<const fu32x4_t*>(a.W1img) + (size_t)wave * KK * 3 * 64 + lane;
-    auto load_w = [&](int c, fu32x4_t (&wv)[F128_KC * 3]) {
+    const fu32x4_t* wimg = reinterpret_cast<const fu32x4_t*>(a.W1img) + (size_t)wave * KK * PER * 64 + lane;
+    auto load_w = [&](int c, fu32x4_t (&wv)[F128_KC * PER]) {
 #pragma unroll
-        for (int q = 0; q < F128_KC * 3; ++q) wv[q] = wimg[((size_t)c * F128_KC * 3 + q) * 64];
+        for (int q = 0; q < F128_KC * PER; ++q) wv[q] = wimg[((size_t)c * F128_KC * PER + q) * 64];
     };
     f32x4_t acc[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const unsigned lds0 = (unsigned)(uintptr_t)smem + lane * 16;
-    auto body = [&](int c, const fu32x4_t (&cur)[F128_KC * 3], fu32x4_t (&nxt)[F128_KC * 3]) {
+    auto body = [&](int c, const fu32x4_t (&cur)[F128_KC * PER], fu32x4_t (&nxt)[F128_KC * PER]) {
         if (c + 1 < nchunk) {                              // chunk c + 1: image fragments and rows, all waited for at the barrier
             if (!(diag & 2u)) load_w(c + 1, nxt);
             if (!(diag & 4u)) issue_x(c + 1, (c + 1) & 1);
@@ -539,14 +544,22 @@ __global__ __launch_bounds__(256, 2) void meta_forward128_kernel(FwdArgs a) {
             asm volatile("" : "+v"(Ac[0]), "+v"(Ac[1]));
             if (!(diag & 1u)) {
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+                for (int r = 0; r < 2; ++r) {
+                    if constexpr (ST == 2) {
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) acc[g * 2 + r] = moc_mfma_half<F16>(Ac[r], cur[kl * 3 + t], acc[g * 2 + r]);
+                        for (int m = 0; m < 4; ++m)
+                            acc[g * 2 + r] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(Ac[r][m]), __uint_as_float(cur[kl][m]),
+                                                                                  acc[g * 2 + r], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) acc[g * 2 + r] = moc_mfma_half<F16>(Ac[r], cur[kl * 3 + t], acc[g * 2 + r]);
+                    }
+                }
             }
         }
         __syncthreads();                                   // chunk c + 1 has landed for everybody; this buffer is free
     };
-    fu32x4_t wA[F128_KC * 3], wB[F128_KC * 3];
+    fu32x4_t wA[F128_KC * PER], wB[F128_KC * PER];
     load_w(0, wA);
     issue_x(0, 0);
     __syncthreads();
@@ -1796,18 +1809,20 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
     }
     dim3 grid(moc_cdiv(s_bound(B), 16), n);
     static const int fwd_variant = getenv("MOC_FORWARD_EVAL") ? atoi(getenv("MOC_FORWARD_EVAL")) : 128;   // diagnostic: 64 = the 64-row kernel
-    if (n >= 4 && B->dtype != MOC_F32 && (B->D * 2) % 512 == 0 && s_bound(B) >= 1024 && fwd_variant == 128 &&
+    if (n >= 4 && (B->D * moc_elem_size(B->dtype)) % 512 == 0 && s_bound(B) >= 1024 && fwd_variant == 128 &&
         !(B->flags & MOC_FORWARD_ROWS64)) {
         // many slides of many selected rows (evaluation): 128 rows per workgroup, rows by LDS-DMA, two workgroups per CU
         static bool attr128 = false;
         if (!attr128) {
-            (void)hipFuncSetAttribute((const void*)meta_forward128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F128_LDS);
-            (void)hipFuncSetAttribute((const void*)meta_forward128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F128_LDS);
+            (void)hipFuncSetAttribute((const void*)meta_forward128_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, F128_LDS);
+            (void)hipFuncSetAttribute((const void*)meta_forward128_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, F128_LDS);
+            (void)hipFuncSetAttribute((const void*)meta_forward128_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, F128_LDS);
             attr128 = true;
         }
         dim3 g128(moc_cdiv(s_bound(B), F128_ROWS), n);
-        if (B->dtype == MOC_F16) meta_forward128_kernel<true><<<g128, 256, F128_LDS, s>>>(a);
-        else meta_forward128_kernel<false><<<g128, 256, F128_LDS, s>>>(a);
+        if (B->dtype == MOC_F16) meta_forward128_kernel<1><<<g128, 256, F128_LDS, s>>>(a);
+        else if (B->dtype == MOC_BF16) meta_forward128_kernel<0><<<g128, 256, F128_LDS, s>>>(a);
+        else meta_forward128_kernel<2><<<g128, 256, F128_LDS, s>>>(a);
         MOC_CHECK_LAUNCH("moc_meta_forward(128)");
         return MOC_OK;
     }

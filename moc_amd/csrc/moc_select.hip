@@ -857,8 +857,10 @@ extern "C" int moc_select(const moc_batch_t* B, moc_stream_t stream) {
     a.compact = (B->flags & MOC_STATS_COMPACT) ? 1 : 0;
     const int ncol = 2 * B->C + 2;
     static const int force = getenv("MOC_SELECT_KERNEL") ? atoi(getenv("MOC_SELECT_KERNEL")) : 0;   // diagnostic: 1 per column, 2 grouped
-    if ((ncol > SG_COLS || force == 2) && force != 1 && !(B->flags & MOC_SELECT_PER_COLUMN) && B->topj <= 1024) {
-        // wide banks: one workgroup per slide and group of SG_COLS columns (select_group_kernel)
+    if ((ncol > SG_COLS || B->n_slides >= 128 || force == 2) && force != 1 && !(B->flags & MOC_SELECT_PER_COLUMN) && B->topj <= 1024) {
+        // wide banks: one workgroup per slide and group of SG_COLS columns (select_group_kernel).  Narrow banks take it for
+        // launches over many slides (evaluation: 202 x 15,000 x 2 classes 73 against 92 us, 3 classes 116 against 145); for a
+        // 32-slide train pass one workgroup per column is the faster one (15 against 47 us: too few workgroups otherwise)
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)select_group_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_BYTES);

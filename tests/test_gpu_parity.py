@@ -614,7 +614,7 @@ def test_full_size_properties(dev):
 
 @pytest.mark.parametrize("rows64", [False, True])
 @pytest.mark.parametrize("dtype,D,C", [(torch.bfloat16, 512, 3), (torch.float16, 512, 3), (torch.bfloat16, 768, 3), (torch.float16, 256, 3),
-                                       (torch.bfloat16, 512, 30), (torch.bfloat16, 1024, 20)])
+                                       (torch.bfloat16, 512, 30), (torch.bfloat16, 1024, 20), (torch.float32, 512, 3), (torch.float32, 256, 30)])
 def test_batched_forward_is_bit_identical_to_one_slide_at_a_time(dev, dtype, D, C, rows64):
     """Many slides at once take the 128-row forward kernel (rows by LDS-DMA, W1 fragments shared by eight row tiles) or,
     with MOC_FORWARD_ROWS64 / fewer selectable rows, the 64-row one (fragments shared by four); the meta-step's one-slide
