@@ -19,9 +19,9 @@ bit-identical to one GPU, hence the reference's AUC; a step is still one slide a
 Minibatch data parallelism (`--train-mode dp`: one slide per rank per synchronous step, the meta-gradient summed over
 the ranks, one Adam step per N slides) is faster but changes the trajectory -- measured AUC deviations of 0.01-0.2
 from the sequential run at every N and learning-rate rule (profiles/round2_dp_auc_study.jsonl), outside the +-0.002
-bar -- so it is an opt-in extension; a default N > 1 run reports it under `minibatch_dp` (strong: the same slides
-sharded, `--scaling`; weak: every rank its own) from shorter runs of the same process, and under `replicas` what N
-independent runs (one per GPU, no communication: the reference's scripts/moc_train.sh) deliver together.
+bar -- so it is an opt-in extension; `--dp-extra` adds it to an N > 1 run under `minibatch_dp` (strong: the same slides
+sharded, `--scaling`; weak: every rank its own) from shorter runs of the same process; every N > 1 run reports under
+`replicas` what N independent runs (one per GPU, no communication: the reference's scripts/moc_train.sh) deliver together.
 
 Prints ONE JSON line on rank 0.  Extra keys: steady_state (>= 50 whole epochs of the same model in the
 same run: what a training run of many epochs sees, whatever --steps was), roofline (dominant kernel =
@@ -96,7 +96,11 @@ def parse():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="--train-mode dp: strong = the same --slides slides sharded over the ranks (the BASELINE metric); "
                          "weak = every rank its own --slides slides")
-    ap.add_argument("--no-dp-extra", action="store_true", help="N > 1, seq: skip the minibatch_dp extra block")
+    ap.add_argument("--dp-extra", action="store_true",
+                    help="N > 1, seq: also measure the opt-in minibatch data-parallel mode (`minibatch_dp` block).  Off by default: its "
+                         "gradient exchange (a private RCCL communicator, or peer-mapped buffers) has never run on two distinct "
+                         "devices -- this pool has one GPU per box -- and a hang there would cost the line its `value`")
+    ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the `replicas` block (N independent runs, no collective)")
     ap.add_argument("--dp-exchange", default="rccl", choices=["rccl", "auto"],
                     help="minibatch data parallelism: rccl = ONE RCCL all-reduce of the flat meta-gradient per step (default: "
                          "the collective is the path that needs no peer mapping); auto = the sum inside the step kernel over "
@@ -528,7 +532,7 @@ def main():
 
     # ---- the modes that are not `value`, from shorter runs of this process, as extra keys (N > 1 only)
     extras = {}
-    if world > 1 and not (main_mode == "seq" and a.no_dp_extra):
+    if world > 1 and (main_mode != "seq" or a.dp_extra):
         del res, loop
         r["res"] = r["loop"] = None
         todo = [m for m in ("dp_strong", "dp_weak") if m != main_mode and not (m == "dp_strong" and a.slides % world)]
@@ -550,7 +554,7 @@ def main():
     # ---- N independent runs, one per GPU, no communication at all: how the reference itself uses several GPUs
     # (scripts/moc_train.sh gives every fold x shot its own process and GPU) -- every run the reference's trajectory
     replicas = None
-    if world > 1 and not a.no_dp_extra:
+    if world > 1 and not a.no_replicas:
         try:
             k3 = max(a.slides, min(a.steps, 10 * a.slides))
             r3 = measure("replicas", k3, min(a.warmup, a.slides), 0)

@@ -48,11 +48,11 @@ def test_one_gpu_line(gpu_device):
 
 
 def test_gpus_2_starts_its_own_ranks_and_reports_the_exact_sequential_mode(gpu_device):
-    d = _bench("--gpus", "2", "--steps", "32", "--warmup", "32", "--no-eval", "--steady-epochs", "2", "--dp-exchange", "auto",
+    d = _bench("--gpus", "2", "--steps", "32", "--warmup", "32", "--no-eval", "--steady-epochs", "2", "--dp-exchange", "auto", "--dp-extra",
                env={"MOC_BENCH_ONE_DEVICE": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 100
     assert d["config"]["parallelism"].startswith("seq2: exact-sequential")
-    assert "rehearsal" in d
+    assert "rehearsal" in d and d["ranks_seen"] == 2 and "rccl_version" in d
     mb = d["minibatch_dp"]
     assert mb["dp_strong"]["value"] > 100 and mb["dp_weak"]["value"] > 100 and mb["dp_strong"]["exchange"] == "p2p"
     assert "NOT within" in mb["note"]
