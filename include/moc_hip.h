@@ -64,7 +64,11 @@ enum { MOC_STATS_COMPACT = 1,
        /* moc_meta_forward over many slides: keep to 64 rows per workgroup (the default for launches of at least four
         * slides with 1024 or more selectable rows on 16-bit bags is 128 rows per workgroup, rows by LDS-DMA); both give
         * the bits of the one-slide kernel -- the bit exists so that tests can say so */
-       MOC_FORWARD_ROWS64 = 8 };
+       MOC_FORWARD_ROWS64 = 8,
+       /* moc_meta_forward on fp32 bags, 16 rows per workgroup: keep to four waves, every wave the whole chain over the
+        * columns of its hidden units (the default splits the columns over four wave groups, sixteen waves: the training
+        * step's forward); the same bits -- the bit exists so that tests can say so */
+       MOC_FORWARD_FOUR_WAVES = 16 };
 
 /* bits of `discard_bits`, in the order of main_moc.py:341-350 */
 enum { MOC_SEL_TOPK = 1, MOC_SEL_DELTA_SOFTMAX = 2, MOC_SEL_DELTA_DIFF = 4, MOC_SEL_BOTTOMK = 8 };

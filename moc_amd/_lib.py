@@ -22,6 +22,7 @@ MOC_STATS_COMPACT = 1
 MOC_SELECT_PER_COLUMN = 2
 MOC_CAND_FROM_STATS = 4
 MOC_FORWARD_ROWS64 = 8
+MOC_FORWARD_FOUR_WAVES = 16
 SEL_BITS = {"topk": 1, "delta_softmax": 2, "delta_diff": 4, "bottomk": 8}
 
 _p = C.c_void_p

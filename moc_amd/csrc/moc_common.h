@@ -186,6 +186,15 @@ extern __device__ unsigned long long g_moc_stamps[128];
             g_moc_stamps[64 + (id)] = __builtin_amdgcn_s_memtime();   /* shader cycles */       \
         }                                                                                      \
     } while (0)
+// the same after everything the stamping wave has in flight (vector and scalar memory, LDS) has arrived: the stamp then
+// marks an ARRIVAL, not an issue (perturbs the kernel: the diagnostic build's business)
+#define MOC_STAMP_DRAIN(id)                                                                     \
+    do {                                                                                       \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x >> 6) == 0)                       \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
+        MOC_STAMP(id);                                                                         \
+    } while (0)
 #else
 #define MOC_STAMP(id) do { } while (0)
+#define MOC_STAMP_DRAIN(id) do { } while (0)
 #endif

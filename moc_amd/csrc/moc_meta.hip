@@ -139,6 +139,15 @@ __global__ __launch_bounds__(256) void w1_image_kernel(const float* W1, int D, u
     w1_image_store(dt, img, D, h, d, W1[e]);
 }
 
+// fp32 bags: one quarter's chain joins the running sum (first quarter: taken as it is), the chain starts over
+__device__ __forceinline__ void fwd_fold_quarter(f32x4_t& tot, f32x4_t& acc, bool first) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        tot[i] = first ? acc[i] : moc_fadd(tot[i], acc[i]);
+        acc[i] = 0.f;
+    }
+}
+
 // grid (ceil(S_bound/16), n): one workgroup = 16 selected rows, wave w = hidden units 16w..16w+15.
 template <bool BF16, bool F16 = false>
 __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
@@ -184,6 +193,11 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
     }
     const int KST = (int)(row_bytes / 64);                        // k-steps over all of D
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    // fp32 bags: the sum over D is formed as ((p0 + p1) + p2) + p3, p_q = the MFMA chain over the q-th quarter of the
+    // columns -- the association of meta_forward_ksplit_kernel, which runs the four chains side by side (same bits)
+    f32x4_t tot = {0.f, 0.f, 0.f, 0.f};
+    const int QS = a.D / 64;                                      // k-steps of 16 columns per quarter
+    int qc = 0, qi = 0;
     for (int u = 0; u < U; ++u) {
         if (u > 0) __syncthreads();                               // every wave is done reading the previous tile
         uint4 xv[4];
@@ -235,10 +249,15 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa.y), __uint_as_float(wv[kq].y), acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa.z), __uint_as_float(wv[kq].z), acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa.w), __uint_as_float(wv[kq].w), acc, 0, 0, 0);
+                    if (++qc == QS) {
+                        qc = 0;
+                        fwd_fold_quarter(tot, acc, qi++ == 0);
+                    }
                 }
             }
         }
     }
+    if constexpr (!BF16) acc = tot;
     MOC_STAMP(1);
     {   // acc[i] = pre-activation of row (lane>>4)*4+i, hidden unit wave*16 + (lane&15)
         const int hcol = wave * 16 + (lane & 15);
@@ -283,6 +302,147 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
         if (a.use_bits & 4u) v = moc_fadd(v, moc_fmul(Gs[r][2], s2));
         if (a.use_bits & 8u) v = moc_fadd(v, moc_fmul(Gs[r][3], s3));
         a.mixed[(int64_t)c * a.stride + base + row0 + r] = v;
+    }
+    MOC_STAMP(2);
+}
+
+// ---- one slide, fp32 bags (the training step of the default storage): the columns split over four wave groups ------
+// meta_forward_kernel<false> is a chain of D/4 v_mfma_f32_16x16x4_f32 per wave (128 x 32 cycles = 1.7 us at D = 512, with
+// three of every four SIMD cycles idle: one wave per SIMD) behind TWO dependent rounds of row loads (2-KiB rows in two
+// 1-KiB units, the second requested after the first has been multiplied) -- 5.5 us from kernel start to the last MFMA
+// against 3.2 us for bf16 bags (phase stamps, profiles/NOTES.md round 3).  Here a workgroup is 16 waves: wave w holds
+// hidden units 16 (w & 3) .. +15 and the (w >> 2)-th QUARTER of the columns, so that the four chains of a hidden tile run
+// side by side on the four waves of a SIMD (32 MFMAs each), every row is requested whole at once (wave w fetches row w:
+// D / 256 sixteen-byte loads per lane, one wave-uniform row id), and the four partial tiles meet in LDS as
+// ((p0 + p1) + p2) + p3 -- the association the 16- and 128-row kernels keep for fp32 bags, hence the same bits.
+// grid (ceil(S_bound/16), n), 1024 threads; D <= 1024.
+constexpr int FKS_PSTR = H + 4;                             // row stride of a partial tile in LDS (floats)
+__host__ __device__ constexpr int fks_lds_bytes(int D) {
+    return 16 * D * 4 + 4 * 16 * FKS_PSTR * 4 + 16 * (H + 1) * 4 + 16 * 4 * 4 + 4 * H * 4;
+}
+// DQ = D / 256: every loop over a row's pieces or a quarter's fragments has a compile-time trip count.  STATS: the candidate
+// scores come from the score pass's statistics through sel_idx (cand_mode != 0: evaluation of a few slides); the training
+// step reads the materialised columns -- no dependent load, no branch between the barrier and the chain.
+template <int DQ, bool STATS>
+__global__ __launch_bounds__(1024) void meta_forward_ksplit_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int D = DQ * 256;
+    uint4* xt = reinterpret_cast<uint4*>(smem);                                     // [16][D/4] chunks, swizzled
+    float* part = reinterpret_cast<float*>(smem + (size_t)16 * D * 4);              // [4][16][FKS_PSTR]
+    float (*Hs)[H + 1] = reinterpret_cast<float (*)[H + 1]>(part + 4 * 16 * FKS_PSTR);
+    float (*Gs)[4] = reinterpret_cast<float (*)[4]>(reinterpret_cast<float*>(Hs) + 16 * (H + 1));
+    float* W2s = reinterpret_cast<float*>(Gs) + 16 * 4;
+    const int b = a.slide0 + blockIdx.y;
+    const int64_t base = a.base_host >= 0 ? a.base_host : a.row_off[b];
+    const int S = a.n_sel[b];
+    const int row0 = blockIdx.x * 16;
+    if (row0 >= S) return;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ht = wave & 3, kq = wave >> 2;
+    MOC_STAMP(0);
+    // this wave's row, whole: the row id is one scalar load, the row D / 256 loads of 1 KiB per wave
+    constexpr int64_t row_bytes = (int64_t)D * 4;
+    constexpr int cpl = DQ;                                  // 16-byte chunks per lane
+    const int sr = min(row0 + wave, S - 1);
+    const int64_t rid = a.sel_row[base + sr];
+    const unsigned char* rp = a.X + rid * row_bytes + lane * 16;
+    MOC_STAMP_DRAIN(3);
+    // W1 image of (hidden tile, quarter): D / 64 fragments of 1 KiB.  (rid >> 63 is zero: the address is made to depend on
+    // the row id so that hipcc cannot hoist these loads above the row id's wait -- they must queue BEHIND the rows.)
+    constexpr int QS = D / 64;
+    const uint4* wi = reinterpret_cast<const uint4*>(a.W1img) + ((size_t)ht * (D / 16) + (size_t)kq * QS) * 64 + lane + (rid >> 63);
+    // (the rows first: loads return in issue order, and the tile must be in LDS before the first MFMA, while the image
+    // fragments -- 128 KiB per workgroup through one CU's 64 B/clk -- may keep arriving under the chain)
+    uint4 xv[cpl];
+#pragma unroll
+    for (int i = 0; i < cpl; ++i) xv[i] = *reinterpret_cast<const uint4*>(rp + i * 1024);
+    uint4 wv[QS];
+#pragma unroll
+    for (int q = 0; q < QS; ++q) wv[q] = wi[q * 64];
+    constexpr int cpr = D / 4;                               // chunks per row
+#pragma unroll
+    for (int i = 0; i < cpl; ++i) xt[wave * cpr + ((lane + i * 64) ^ wave)] = xv[i];     // chunk c of row r at c ^ r (r < 16)
+    MOC_STAMP(5);
+    __syncthreads();
+    MOC_STAMP(6);
+    // epilogue operands that do not depend on the product: requested now (straight-line code up to the barrier), consumed
+    // after the chain
+    const int C = a.C;
+    float pre_c[4] = {0.f, 0.f, 0.f, 0.f};
+    const int er = t & 15, ec = t >> 4;
+    const bool e_ok = ec < C && row0 + er < S;
+    if constexpr (STATS) {
+        if (e_ok) {
+            const float* cd = cand_row(a, base, row0 + er);
+            float m1, rden;
+            cand_row_norm(a, cd, m1, rden);
+            cand_class_scores(a, cd, ec, m1, rden, pre_c[0], pre_c[1]);
+            cand_row_scores(a, cd, pre_c[2], pre_c[3]);
+        }
+    } else {                                                 // unconditional (clamped): exact vmcnt counts under the chain
+        const float* cd = a.cand + base + min(row0 + er, S - 1);
+        const int cc = ec < C ? ec : C - 1;
+        pre_c[0] = cd[(int64_t)cc * a.stride];
+        pre_c[1] = cd[(int64_t)(C + cc) * a.stride];
+        pre_c[2] = cd[(int64_t)(2 * C) * a.stride];
+        pre_c[3] = cd[(int64_t)(2 * C + 1) * a.stride];
+    }
+    const float w2_pre = a.W2[t & 255];
+    const float bias = a.b1[t & 63];
+    const float b2_pre = a.b2[t & 3];
+    __builtin_amdgcn_sched_barrier(0);                       // (hipcc otherwise sinks these requests below the chain)
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int r = lane & 15;
+        const uint4* xr = xt + r * cpr;
+        const int c0 = kq * QS * 4 + (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < QS; ++q) {
+            const uint4 xa = xr[(c0 + q * 4) ^ r];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa.x), __uint_as_float(wv[q].x), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa.y), __uint_as_float(wv[q].y), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa.z), __uint_as_float(wv[q].z), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(xa.w), __uint_as_float(wv[q].w), acc, 0, 0, 0);
+        }
+    }
+#ifdef MOC_STAMPS
+    asm volatile("v_add_f32 %0, %0, 0" : "+v"(acc[0]));      // the stamp waits for the chain
+#endif
+    MOC_STAMP(1);
+    {   // acc[i] = partial pre-activation of row (lane>>4)*4+i, hidden unit ht*16 + (lane&15), quarter kq
+        float* pp = part + (size_t)(kq * 16 + (lane >> 4) * 4) * FKS_PSTR + ht * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pp[i * FKS_PSTR] = acc[i];
+        if (t < 4 * H) W2s[t] = w2_pre;
+    }
+    __syncthreads();
+    {   // thread = (row t >> 6, hidden unit t & 63)
+        const int r = t >> 6, h = t & 63;
+        const float* pp = part + (size_t)r * FKS_PSTR + h;
+        const float pre = moc_fadd(moc_fadd(moc_fadd(pp[0], pp[16 * FKS_PSTR]), pp[32 * FKS_PSTR]), pp[48 * FKS_PSTR]);
+        const float hv = fmaxf(moc_fadd(pre, bias), 0.f);
+        Hs[r][h] = hv;
+        if (a.H1 && row0 + r < S) a.H1[(base + row0 + r) * H + h] = hv;      // needed by the backward pass only
+    }
+    __syncthreads();
+    if (t < 64) {
+        const int r = t >> 2, i = t & 3;
+        float z = 0.f;
+        for (int h = 0; h < H; ++h) z = fmaf(Hs[r][h], W2s[i * H + h], z);
+        z += b2_pre;
+        const float g = 1.f / (1.f + expf(-z));
+        Gs[r][i] = g;
+        if (a.gates && row0 + r < S) a.gates[(base + row0 + r) * 4 + i] = g;
+    }
+    __syncthreads();
+    if (e_ok) {
+        float v = 0.f;   // 0 + x == x exactly, so this is the reference's running sum in both modes
+        if (a.use_bits & 1u) v = moc_fadd(v, moc_fmul(Gs[er][0], pre_c[0]));
+        if (a.use_bits & 2u) v = moc_fadd(v, moc_fmul(Gs[er][1], pre_c[1]));
+        if (a.use_bits & 4u) v = moc_fadd(v, moc_fmul(Gs[er][2], pre_c[2]));
+        if (a.use_bits & 8u) v = moc_fadd(v, moc_fmul(Gs[er][3], pre_c[3]));
+        a.mixed[(int64_t)ec * a.stride + base + row0 + er] = v;
     }
     MOC_STAMP(2);
 }
@@ -517,6 +677,8 @@ __global__ __launch_bounds__(256, 2) void meta_forward128_kernel(FwdArgs a) {
     f32x4_t acc[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t tot[ST == 2 ? 8 : 1] = {};                     // fp32 bags: running sum of the column quarters (meta_forward_kernel)
+    const int qchunks = nchunk / 4;                        // chunks per quarter (D a multiple of 256)
     const unsigned lds0 = (unsigned)(uintptr_t)smem + lane * 16;
     auto body = [&](int c, const fu32x4_t (&cur)[F128_KC * PER], fu32x4_t (&nxt)[F128_KC * PER]) {
         if (c + 1 < nchunk) {                              // chunk c + 1: image fragments and rows, all waited for at the barrier
@@ -557,6 +719,13 @@ __global__ __launch_bounds__(256, 2) void meta_forward128_kernel(FwdArgs a) {
                 }
             }
         }
+        if constexpr (ST == 2) {                           // fp32 bags: ((p0 + p1) + p2) + p3 over the quarters of the columns
+            if ((c + 1) % qchunks == 0) {
+                const bool first = c + 1 == qchunks;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) fwd_fold_quarter(tot[r], acc[r], first);
+            }
+        }
         __syncthreads();                                   // chunk c + 1 has landed for everybody; this buffer is free
     };
     fu32x4_t wA[F128_KC * PER], wB[F128_KC * PER];
@@ -569,6 +738,10 @@ __global__ __launch_bounds__(256, 2) void meta_forward128_kernel(FwdArgs a) {
     }
     {   // acc[r][i] = pre-activation of row r*16 + (lane>>4)*4 + i, hidden unit wave*16 + (lane&15)
         const int hcol = wave * 16 + (lane & 15);
+        if constexpr (ST == 2) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = tot[r];
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
@@ -1831,6 +2004,32 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
         if (B->dtype == MOC_F16) meta_forward64_kernel<true><<<g64, 256, 0, s>>>(a);
         else meta_forward64_kernel<false><<<g64, 256, 0, s>>>(a);
         MOC_CHECK_LAUNCH("moc_meta_forward(64)");
+        return MOC_OK;
+    }
+    if (B->dtype == MOC_F32 && B->D <= 1024 && B->C <= 64 && !(B->flags & MOC_FORWARD_FOUR_WAVES)) {
+        // fp32 bags: the columns split over four wave groups (same bits as the four-wave kernel)
+        static bool attr_ks = false;
+        if (!attr_ks) {
+            (void)hipFuncSetAttribute((const void*)meta_forward_ksplit_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, fks_lds_bytes(768));
+            (void)hipFuncSetAttribute((const void*)meta_forward_ksplit_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, fks_lds_bytes(1024));
+            (void)hipFuncSetAttribute((const void*)meta_forward_ksplit_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, fks_lds_bytes(768));
+            (void)hipFuncSetAttribute((const void*)meta_forward_ksplit_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, fks_lds_bytes(1024));
+            attr_ks = true;
+        }
+        const int lds = fks_lds_bytes(B->D);
+#define MOC_KS_LAUNCH(DQ)                                                                        \
+    do {                                                                                         \
+        if (a.cand_mode) meta_forward_ksplit_kernel<DQ, true><<<grid, 1024, lds, s>>>(a);         \
+        else meta_forward_ksplit_kernel<DQ, false><<<grid, 1024, lds, s>>>(a);                    \
+    } while (0)
+        switch (B->D / 256) {
+            case 1: MOC_KS_LAUNCH(1); break;
+            case 2: MOC_KS_LAUNCH(2); break;
+            case 3: MOC_KS_LAUNCH(3); break;
+            default: MOC_KS_LAUNCH(4); break;
+        }
+#undef MOC_KS_LAUNCH
+        MOC_CHECK_LAUNCH("moc_meta_forward(ksplit)");
         return MOC_OK;
     }
     if (B->dtype == MOC_F16) meta_forward_kernel<true, true><<<grid, 256, 0, s>>>(a);

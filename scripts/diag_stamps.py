@@ -10,10 +10,11 @@ torch.set_num_threads(8)
 from moc_amd import engine, main_moc as M, synth
 from moc_amd._lib import lib
 dev = torch.device("cuda:0")
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
 Cc, D, j, K = 2, 512, 400, 10
 W, We = synth.make_bank(1234, D, Cc)
 M.set_classifier_bank(W.to(dev), We.to(dev))
-bags = [synth.make_bag_device(1234 + i, 15000, D, We, Cc, i % Cc, dev, torch.bfloat16) for i in range(32)]
+bags = [synth.make_bag_device(1234 + i, 15000, D, We, Cc, i % Cc, dev, DT) for i in range(32)]
 res = M.ResidentBags(bags, [i % Cc for i in range(32)], dev)
 torch.manual_seed(0)
 model = M.senet(D, 4).to(dev); opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
@@ -23,7 +24,7 @@ batch, lab = plan["batch"], plan["labels"]
 m, kept = engine.draw_row_masks(batch.total); batch.set_mask(m, kept); batch.phase_a(bank)
 meta = engine.MetaState(model, opt)
 h = lib(); h.moc_debug_stamps.restype = C.c_int; h.moc_debug_stamps.argtypes = [C.c_void_p, C.c_int]
-names = {0: "fwd begin", 1: "fwd mfma done", 2: "fwd end", 10: "pool begin", 11: "pool wave-max done", 12: "pool candidates done",
+names = {0: "fwd begin", 3: "fwd row id here", 5: "fwd tile in LDS", 6: "fwd barrier", 1: "fwd mfma done", 2: "fwd end", 10: "pool begin", 11: "pool wave-max done", 12: "pool candidates done",
          13: "pool extraction done", 14: "pool CE done", 15: "pool W2 staged", 16: "pool pairs done", 17: "pool dh done", 18: "pool end",
          }   # (the W1 update is part of the pool kernel now: one-launch step)
 acc = {}

@@ -651,6 +651,45 @@ def test_batched_forward_is_bit_identical_to_one_slide_at_a_time(dev, dtype, D, 
         assert torch.equal(together["gates"][o:o + n], t["gates"][o:o + n])
 
 
+@pytest.mark.parametrize("D,C,j", [(512, 2, 400), (256, 3, 150), (768, 5, 90), (1024, 30, 40), (512, 64, 20)])
+def test_fp32_forward_split_over_four_wave_groups_gives_the_four_wave_bits(dev, D, C, j):
+    """fp32 bags: the one-slide forward of the training step splits the columns over four wave groups (sixteen waves, every
+    row requested whole at once); with MOC_FORWARD_FOUR_WAVES it is the four-wave kernel, one chain per wave over all the
+    columns, folded into the same ((p0 + p1) + p2) + p3: hidden layer, gates and mixed scores bit for bit, one slide at a
+    time and several per launch, short last tiles included."""
+    M, E = _mm(), _engine()
+    from moc_amd import _lib
+    K = 10
+    W, We = synth.make_bank(72, D, C)
+    sizes = [900, 1500, 64, 17, 2100, 333]
+    bags = [synth.make_bag_device(7200 + i, n, D, We, C, i % C, dev, torch.float32) for i, n in enumerate(sizes)]
+    torch.manual_seed(4)
+    model = M.senet(D, 4).to(dev)
+    X, _ = M._pack(bags, dev, torch.float32)
+    b = E.SlideBatch(X, sizes, C, C + 4, j, K)
+    b.phase_a(E.Bank.get(W.to(dev), We.to(dev), torch.float32, dev))
+    meta = E.MetaState(model)
+    t = b.meta_ws()[0]
+    out = {}
+    for four in (False, True):
+        b.c.flags = (b.c.flags & ~_lib.MOC_FORWARD_FOUR_WAVES) | (_lib.MOC_FORWARD_FOUR_WAVES if four else 0)
+        for k in ("mixed", "H1", "gates"):
+            t[k].zero_()
+        for i in range(len(sizes)):
+            E.meta_forward(b, meta, i, 1, 15)
+        torch.cuda.synchronize()
+        out[four] = {k: t[k].clone() for k in ("mixed", "H1", "gates")}
+        for k in ("mixed", "H1", "gates"):
+            t[k].zero_()
+        E.meta_forward(b, meta, 1, 3, 15)          # three slides per launch: still the 16-row kernels
+        torch.cuda.synchronize()
+        out[four, 3] = {k: t[k].clone() for k in ("mixed", "H1", "gates")}
+    assert float(out[False]["H1"].abs().sum()) > 0
+    for k in ("mixed", "H1", "gates"):
+        assert torch.equal(out[False][k], out[True][k]), k
+        assert torch.equal(out[False, 3][k], out[True, 3][k]), k
+
+
 # ------------------------------------------------------------------ paths the fixtures do not reach
 @pytest.mark.parametrize("C,K,j,D,dtype,sizes", [
     (2, 20, 100, 512, torch.float32, [900, 700, 1100]),        # K > 16: general pooling + step kernels
