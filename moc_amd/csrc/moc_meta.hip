@@ -1041,10 +1041,14 @@ __device__ __forceinline__ void ce_wave0(const FinishArgs& a, int b, int C, int 
 // VPT = scores per thread per class (S <= 1024 * VPT); CE_OFF = widest xor offset of the cross-entropy
 // reduction (8: C <= 16 on lanes 0..15; 32: C <= 64 on the whole wave).
 // CG = classes handled per round (CG * VPT 64-bit keys live in registers).
-template <int VPT = PS_VPT, int CE_OFF = 8, int CG = 4>
+// `after_first_loads()` is called once, right after the first group's score loads have been ISSUED: the place for the
+// caller's own prefetches (parameters, moments) -- loads return in issue order, so whatever is requested before the
+// scores delays the first thing this kernel waits for.
+struct PoolNoHook { __device__ __forceinline__ void operator()() const {} };
+template <int VPT = PS_VPT, int CE_OFF = 8, int CG = 4, typename Hook = PoolNoHook>
 __device__ __forceinline__ int pool_phase(const FinishArgs& a, int b, const PoolLds& L, int PS_CAP, bool write_out,
                                           float* pooled_out, int32_t* topk_idx_out, int32_t* topk_cnt_out,
-                                          int64_t* base_out) {
+                                          int64_t* base_out, Hook after_first_loads = Hook()) {
     const int C = a.C, K = a.K;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long* list = L.list;
@@ -1065,24 +1069,31 @@ __device__ __forceinline__ int pool_phase(const FinishArgs& a, int b, const Pool
     const int k = K < S ? K : S;
     for (int c0 = 0; c0 < C; c0 += CG) {
         unsigned long long key[CG][VPT];
+        {   // the group's loads, ALL of them before the first wait: unconditional (an absent class re-reads the last one,
+            // a slot past the slide its last slot), masked afterwards -- a branch per class made every class its own
+            // memory round trip
+            float v[CG][VPT];
 #pragma unroll
-        for (int cc = 0; cc < CG; ++cc) {
-#pragma unroll
-            for (int q = 0; q < VPT; ++q) key[cc][q] = 0ull;
-            if (c0 + cc < C) {                                   // uniform: no work for absent classes
-                const float* col = a.mixed_in + (int64_t)(c0 + cc) * a.stride + base;
-                float v[VPT];
-#pragma unroll
-                for (int q = 0; q < VPT; ++q) {
-                    const int i = q * 1024 + (int)threadIdx.x;
-                    v[q] = col[i < seg ? i : seg - 1];
-                }
+            for (int cc = 0; cc < CG; ++cc) {
+                const int cl = c0 + cc < C ? c0 + cc : C - 1;
+                const float* col = a.mixed_in + (int64_t)cl * a.stride + base;
 #pragma unroll
                 for (int q = 0; q < VPT; ++q) {
                     const int i = q * 1024 + (int)threadIdx.x;
-                    key[cc][q] = i < S ? ((unsigned long long)moc_key_desc(v[q]) << 32) | (unsigned)(~(unsigned)i) : 0ull;
+                    v[cc][q] = col[i < seg ? i : seg - 1];
                 }
             }
+            if (c0 == 0) {
+                after_first_loads();
+                __builtin_amdgcn_sched_barrier(0);                // (hipcc otherwise sinks the hook's requests past the barriers below)
+            }
+#pragma unroll
+            for (int cc = 0; cc < CG; ++cc)
+#pragma unroll
+                for (int q = 0; q < VPT; ++q) {
+                    const int i = q * 1024 + (int)threadIdx.x;
+                    key[cc][q] = (c0 + cc < C && i < S) ? ((unsigned long long)moc_key_desc(v[cc][q]) << 32) | (unsigned)(~(unsigned)i) : 0ull;
+                }
         }
 #pragma unroll
         for (int cc = 0; cc < CG; ++cc) {
@@ -1339,78 +1350,152 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
     float* H1s = dz + (size_t)C * K * 4;                                             // [P][H]
     float* dhs = H1s + (size_t)C * K * H;                                            // [P][H]
     float* W2s = dhs + (size_t)C * K * H;                                            // [4][H]
-    int* sidx_s = reinterpret_cast<int*>(W2s + 4 * H);                               // [P]
-    float* xs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(sidx_s + C * K) + 15) & ~(uintptr_t)15);   // [P][D], 16-B aligned
+    // (offsets from smem, which is 16-byte aligned, not address arithmetic through integers: the latter loses the LDS
+    // address space and every access through the pointer becomes a flat_ operation)
+    const size_t row_off = ((size_t)(reinterpret_cast<unsigned char*>(W2s + 4 * H) - smem) + 7) & ~(size_t)7;
+    int64_t* row_s = reinterpret_cast<int64_t*>(smem + row_off);                     // [P] bag rows of the pairs
+    float* xs = reinterpret_cast<float*>(smem + ((row_off + (size_t)C * K * 8 + 15) & ~(size_t)15));             // [P][D], 16-B aligned
     MOC_STAMP(10);
-    // operands that do not depend on this slide's scores: requested first, consumed last.
     // thread t: column d = t % D' of hidden units h_lo + 2*(t / D') + {0, 1}, D' = min(D, 512)
     const int t = threadIdx.x;
     const int dcols = D < 512 ? D : 512;                 // columns covered per sweep by 1024 threads (2 h each)
     const int hh = t / dcols, dl = t - hh * dcols;       // hh in {0, 1} when dcols == 512
     const bool own = hh < 2;                             // D < 512: the threads beyond 2*D idle in the W1 part
-    float pw[2][2], pm[2][2], pv[2][2];                  // [h sub-index][d sweep]  (D <= 1024)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int sw = 0; sw < 2; ++sw) {
-            const int d = dl + sw * dcols;
-            pw[j][sw] = pm[j][sw] = pv[j][sw] = 0.f;
-            if (own && d < D && a.apply_adam) {
-                const int e = (h_lo + hh * 2 + j) * D + d;
-                pw[j][sw] = g.W1[e]; pm[j][sw] = g.m_W1[e]; pv[j][sw] = g.v_W1[e];
-            }
-        }
-    float pW = 0.f, pM = 0.f, pV = 0.f;                  // workgroup 0: W2 / b2 / b1 element of this thread
     const AdamCoef ak = step_coef(a);
-    if (t < 4 * H) W2s[t] = a.W2[t];
-    if (wg == 0 && a.apply_adam) {
-        if (t < 4 * H) { pW = W2s[t]; pM = a.m_W2[t]; pV = a.v_W2[t]; }
-        else if (t < 4 * H + 4) { pW = a.b2[t - 4 * H]; pM = a.m_b2[t - 4 * H]; pV = a.v_b2[t - 4 * H]; }
-        else if (t >= 320 && t < 320 + H) { pW = a.b1[t - 320]; pM = a.m_b1[t - 320]; pV = a.v_b1[t - 320]; }
-    }
+    // The parameters and moments this workgroup steps are requested further down, just before the gradient loop that
+    // hides them, and W2 with the pairs' gathers: at the top they sat in front of the slide's scores -- the first thing
+    // the kernel waits for, and loads return in issue order -- and held 12 registers through the pooling.
     int64_t base;
     const PoolLds L = {list, wmax, pooled_s, dpool, ncand, topk_s};
     const int k = pool_phase(a, b, L, PS_CAP, wg == 0, pooled_out, topk_idx_out, topk_cnt_out, &base);
     __syncthreads();
     MOC_STAMP(15);
-    // ---- pairs: position of each pair's row, then one round of gathers (dz operands, H1, bag rows)
+    // ---- pairs: TWO rounds of gathers.  Round 1 -- everything that needs only a pair's position among the selected
+    // rows (its row id, its gate operands, its hidden row), W2 and the parameters this workgroup steps -- is requested in
+    // one go, straight from topk_s; round 2 the bag rows, a wave per pair (two pairs in flight per wave).  Sixteen waves
+    // share one CU here: an instruction every thread executes costs the workgroup 16 issue cycles, so each part runs on
+    // the waves that have work for it and nowhere else, and nothing divides.
     const int P = C * k;
-    for (int p = t; p < P; p += 1024) sidx_s[p] = topk_s[(p / k) * K + (p - (p / k) * k)];
-    __syncthreads();
-    for (int e = t; e < P * 4; e += 1024) {               // dz[p][i]
-        const int p = e >> 2, i = e & 3, c = p / k, sidx = sidx_s[p];
-        const float* cd = a.cand + base + sidx;
-        const float sc = i == 0 ? cd[(int64_t)c * a.stride] : i == 1 ? cd[(int64_t)(C + c) * a.stride]
-                       : i == 2 ? cd[(int64_t)(2 * C) * a.stride] : cd[(int64_t)(2 * C + 1) * a.stride];
-        const float lam = a.gates[(base + sidx) * 4 + i];
-        const float dlam = (a.use_bits >> i & 1u) ? (dpool[c] / (float)k) * sc : 0.f;
-        dz[e] = dlam * lam * (1.f - lam);
-    }
-    {   // H1 of the pairs: workgroup 0 needs all H columns (b1, W2), the others their 4
-        const int hn = wg == 0 ? H : 4, h0 = wg == 0 ? 0 : h_lo;
-        for (int e = t; e < P * hn; e += 1024) {
-            const int p = e / hn, h = h0 + (e - p * hn);
-            H1s[p * H + h] = a.H1[(base + sidx_s[p]) * H + h];
+    float pw[2][2], pm[2][2], pv[2][2];                  // [h sub-index][d sweep]  (D <= 1024): consumed by the Adam update
+    float pW = 0.f, pM = 0.f, pV = 0.f;                  // workgroup 0: W2 / b2 / b1 element of this thread
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int sw = 0; sw < 2; ++sw) pw[j][sw] = pm[j][sw] = pv[j][sw] = 0.f;
+    if (P > 0) {                                         // (uniform)
+        // pairs per class k <= 16, pair numbers < 256: p / k = (p * ceil(2^16 / k)) >> 16 exactly
+        const unsigned kinv = (65536u + (unsigned)k - 1u) / (unsigned)k;
+        auto topk_of = [&](int pp) { const int c = (int)(((unsigned)pp * kinv) >> 16); return topk_s[c * K + (pp - c * k)]; };
+        int64_t rid = 0;
+        if (t < P) rid = a.sel_row[base + topk_of(t)];
+        float sc = 0.f, lam = 0.f;
+        const int dp = t >> 2, di = t & 3, dc = (int)(((unsigned)dp * kinv) >> 16);     // P <= 256: one element of dz per thread
+        if (t < P * 4) {
+            const int dsidx = topk_s[dc * K + (dp - dc * k)];
+            const int dcol = di == 0 ? dc : di == 1 ? C + dc : di == 2 ? 2 * C : 2 * C + 1;
+            sc = a.cand[(int64_t)dcol * a.stride + base + dsidx];
+            lam = a.gates[(base + dsidx) * 4 + di];
         }
-    }
-    {   // bag rows of the pairs -> fp32 in LDS, whole rows, contiguous
-        const int vpr = D / 4;                             // 4-element groups per row
-        for (int e = t; e < P * vpr; e += 1024) {
-            const int p = e / vpr, v = e - p * vpr;
-            const int64_t row = a.sel_row[base + sidx_s[p]];
-            float4 o;
-            if (a.xdt == MOC_F16) {
-                const uint2 raw = *reinterpret_cast<const uint2*>(a.X + (row * D + v * 4) * 2);
-                o.x = moc_f16_to_f32((uint16_t)raw.x); o.y = moc_f16_to_f32((uint16_t)(raw.x >> 16));
-                o.z = moc_f16_to_f32((uint16_t)raw.y); o.w = moc_f16_to_f32((uint16_t)(raw.y >> 16));
-            } else if (a.xdt == MOC_BF16) {
-                const uint2 raw = *reinterpret_cast<const uint2*>(a.X + (row * D + v * 4) * 2);
-                o.x = __uint_as_float(raw.x << 16); o.y = __uint_as_float(raw.x & 0xFFFF0000u);
-                o.z = __uint_as_float(raw.y << 16); o.w = __uint_as_float(raw.y & 0xFFFF0000u);
-            } else {
-                o = *reinterpret_cast<const float4*>(a.X + (row * D + v * 4) * 4);
+        float w2r = 0.f;
+        if (t < 4 * H) w2r = a.W2[t];
+        // H1 of the pairs: workgroup 0 needs all H columns (b1, W2), the others their 4
+        const int hsh = wg == 0 ? 6 : 2, hn = 1 << hsh, h0 = wg == 0 ? 0 : h_lo, nh = P << hsh;
+        float hv0 = 0.f, hv1 = 0.f;
+        if (t < nh) hv0 = a.H1[(base + topk_of(t >> hsh)) * H + h0 + (t & (hn - 1))];
+        if (t + 1024 < nh) hv1 = a.H1[(base + topk_of((t + 1024) >> hsh)) * H + h0 + (t & (hn - 1))];
+        if (a.apply_adam) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int sw = 0; sw < 2; ++sw) {
+                    const int d = dl + sw * dcols;
+                    if (own && d < D) {
+                        const int e = (h_lo + hh * 2 + j) * D + d;
+                        pw[j][sw] = g.W1[e]; pm[j][sw] = g.m_W1[e]; pv[j][sw] = g.v_W1[e];
+                    }
+                }
+            if (wg == 0) {
+                if (t < 4 * H) { pM = a.m_W2[t]; pV = a.v_W2[t]; }
+                else if (t < 4 * H + 4) { pW = a.b2[t - 4 * H]; pM = a.m_b2[t - 4 * H]; pV = a.v_b2[t - 4 * H]; }
+                else if (t >= 320 && t < 320 + H) { pW = a.b1[t - 320]; pM = a.m_b1[t - 320]; pV = a.v_b1[t - 320]; }
             }
-            *reinterpret_cast<float4*>(xs + (size_t)p * D + v * 4) = o;
+        }
+        if (t < P) row_s[t] = rid;
+        if (t < P * 4) {
+            const float dlam = (a.use_bits >> di & 1u) ? (dpool[dc] / (float)k) * sc : 0.f;
+            dz[t] = dlam * lam * (1.f - lam);
+        }
+        if (t < 4 * H) {
+            W2s[t] = w2r;
+            if (wg == 0) pW = w2r;
+        }
+        if (t < nh) H1s[(t >> hsh) * H + h0 + (t & (hn - 1))] = hv0;
+        if (t + 1024 < nh) H1s[((t + 1024) >> hsh) * H + h0 + (t & (hn - 1))] = hv1;
+        for (int e = t + 2048; e < nh; e += 1024) {        // workgroup 0 with more than 32 pairs
+            const int pp = e >> hsh, h = h0 + (e & (hn - 1));
+            H1s[pp * H + h] = a.H1[(base + topk_of(pp)) * H + h];
+        }
+        __syncthreads();
+        // bag rows of the pairs -> fp32 in LDS: wave w takes pairs w, w + 16 (both in flight), w + 32, ...; a lane the
+        // 16-byte (16-bit storage: 8-byte) pieces lane, lane + 64, ... of the row -- D / 256 of them
+        const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+        const int dq = D >> 8;                             // 1..4
+        const int esz = a.xdt == MOC_F32 ? 4 : 2;
+        for (int p0 = wave; p0 < P; p0 += 32) {
+            const int p1 = p0 + 16;
+            const bool two = p1 < P;
+            const unsigned char* r0 = a.X + row_s[p0] * (int64_t)D * esz;
+            const unsigned char* r1 = a.X + row_s[two ? p1 : p0] * (int64_t)D * esz;
+            float* x0 = xs + (size_t)p0 * D + lane * 4;
+            float* x1 = xs + (size_t)p1 * D + lane * 4;
+            if (a.xdt == MOC_F32) {
+                // (named pieces: hipcc keeps an array written under a condition in scratch)
+                float4 a0 = {}, a1 = {}, a2 = {}, a3 = {}, b0 = {}, b1v = {}, b2v = {}, b3 = {};
+                const float4* q0 = reinterpret_cast<const float4*>(r0) + lane;
+                const float4* q1 = reinterpret_cast<const float4*>(r1) + lane;
+                a0 = q0[0]; b0 = q1[0];
+                if (dq > 1) { a1 = q0[64]; b1v = q1[64]; }
+                if (dq > 2) { a2 = q0[128]; b2v = q1[128]; }
+                if (dq > 3) { a3 = q0[192]; b3 = q1[192]; }
+                float4* y0 = reinterpret_cast<float4*>(x0);
+                float4* y1 = reinterpret_cast<float4*>(x1);
+                y0[0] = a0;
+                if (dq > 1) y0[64] = a1;
+                if (dq > 2) y0[128] = a2;
+                if (dq > 3) y0[192] = a3;
+                if (two) {
+                    y1[0] = b0;
+                    if (dq > 1) y1[64] = b1v;
+                    if (dq > 2) y1[128] = b2v;
+                    if (dq > 3) y1[192] = b3;
+                }
+            } else {
+                const bool f16 = a.xdt == MOC_F16;
+                auto widen = [&](uint2 raw) {
+                    float4 o;
+                    if (f16) {
+                        o.x = moc_f16_to_f32((uint16_t)raw.x); o.y = moc_f16_to_f32((uint16_t)(raw.x >> 16));
+                        o.z = moc_f16_to_f32((uint16_t)raw.y); o.w = moc_f16_to_f32((uint16_t)(raw.y >> 16));
+                    } else {
+                        o.x = __uint_as_float(raw.x << 16); o.y = __uint_as_float(raw.x & 0xFFFF0000u);
+                        o.z = __uint_as_float(raw.y << 16); o.w = __uint_as_float(raw.y & 0xFFFF0000u);
+                    }
+                    return o;
+                };
+                uint2 u0[4], u1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < dq) {
+                        u0[i] = *reinterpret_cast<const uint2*>(r0 + (lane + i * 64) * 8);
+                        u1[i] = *reinterpret_cast<const uint2*>(r1 + (lane + i * 64) * 8);
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < dq) {
+                        *reinterpret_cast<float4*>(x0 + i * 256) = widen(u0[i]);
+                        if (two) *reinterpret_cast<float4*>(x1 + i * 256) = widen(u1[i]);
+                    }
+            }
         }
     }
     __syncthreads();
@@ -2112,7 +2197,7 @@ int launch_pool_finish(const moc_batch_t* B, const moc_meta_t* M, const moc_meta
 
 size_t fused_step_smem(const moc_batch_t* B, int cap) {
     const size_t C = B->C, K = B->topk, PK = C * K;
-    return C * cap * 8 + C * 16 * 8 + C * 4 * 3 + C * K * 4 + PK * (4 * 4 + 2 * H * 4) + 4 * H * 4 + PK * 4 + 16 +
+    return C * cap * 8 + C * 16 * 8 + C * 4 * 3 + C * K * 4 + PK * (4 * 4 + 2 * H * 4) + 4 * H * 4 + PK * 8 + 16 +
            PK * (size_t)B->D * 4;
 }
 
