@@ -1107,11 +1107,11 @@ __device__ __forceinline__ int pool_phase(const FinishArgs& a, int b, const Pool
         }
         __syncthreads();
         MOC_STAMP(11);
-        // threshold = K-th largest wave maximum (keys are unique; 0 = empty wave), then candidates
-#pragma unroll
-        for (int cc = 0; cc < CG; ++cc) {
-            const int c = c0 + cc;
-            if (c >= C) break;
+        // threshold = K-th largest wave maximum (keys are unique; 0 = empty wave): wave cc finds class c0 + cc's and leaves
+        // it in the class's first wmax slot -- ONE wave per class, side by side on different SIMDs, not all sixteen each
+        // for every class (an instruction all sixteen waves execute costs the CU four times one wave's)
+        if (wave < CG && c0 + wave < C) {
+            const int c = c0 + wave;
             const unsigned long long mine = wmax[c * 16 + (lane & 15)];
             int rank = 0;
 #pragma unroll
@@ -1124,6 +1124,16 @@ __device__ __forceinline__ int pool_phase(const FinishArgs& a, int b, const Pool
                 const unsigned hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), src, 64);
                 T0 = ((unsigned long long)hi << 32) | lo;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // every lane's reads of the slots are done
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) wmax[c * 16] = T0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < CG; ++cc) {
+            const int c = c0 + cc;
+            if (c >= C) break;
+            const unsigned long long T0 = wmax[c * 16];
 #pragma unroll
             for (int q = 0; q < VPT; ++q) {
                 const unsigned long long v = key[cc][q];
