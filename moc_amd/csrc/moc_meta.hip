@@ -1349,7 +1349,10 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FinishArgs& a = g.f;
     const int b = a.slide0, C = a.C, K = a.K, D = a.D;
-    const int wg = blockIdx.x, h_lo = wg * 4;
+    // HW hidden units of W1 per workgroup: 4 (16 workgroups: the in-kernel gradient exchange has 16 channels) or 2 (32
+    // workgroups: half the Adam arithmetic per thread -- sixteen waves on one CU make that the kernel's last 2 us)
+    const int HW = H / (int)gridDim.x, JN = HW >> 1;
+    const int wg = blockIdx.x, h_lo = wg * HW;
     unsigned long long* list = reinterpret_cast<unsigned long long*>(smem);          // [C][PS_CAP]
     unsigned long long* wmax = list + (size_t)C * PS_CAP;                           // [C][16]
     float* pooled_s = reinterpret_cast<float*>(wmax + (size_t)C * 16);               // [C]
@@ -1366,7 +1369,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
     int64_t* row_s = reinterpret_cast<int64_t*>(smem + row_off);                     // [P] bag rows of the pairs
     float* xs = reinterpret_cast<float*>(smem + ((row_off + (size_t)C * K * 8 + 15) & ~(size_t)15));             // [P][D], 16-B aligned
     MOC_STAMP(10);
-    // thread t: column d = t % D' of hidden units h_lo + 2*(t / D') + {0, 1}, D' = min(D, 512)
+    // thread t: column d = t % D' of hidden units h_lo + JN*(t / D') + {0 .. JN-1}, D' = min(D, 512)
     const int t = threadIdx.x;
     const int dcols = D < 512 ? D : 512;                 // columns covered per sweep by 1024 threads (2 h each)
     const int hh = t / dcols, dl = t - hh * dcols;       // hh in {0, 1} when dcols == 512
@@ -1409,7 +1412,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
         float w2r = 0.f;
         if (t < 4 * H) w2r = a.W2[t];
         // H1 of the pairs: workgroup 0 needs all H columns (b1, W2), the others their 4
-        const int hsh = wg == 0 ? 6 : 2, hn = 1 << hsh, h0 = wg == 0 ? 0 : h_lo, nh = P << hsh;
+        const int hsh = wg == 0 ? 6 : JN, hn = 1 << hsh, h0 = wg == 0 ? 0 : h_lo, nh = P << hsh;   // (HW = 4, 2 = 1 << JN)
         float hv0 = 0.f, hv1 = 0.f;
         if (t < nh) hv0 = a.H1[(base + topk_of(t >> hsh)) * H + h0 + (t & (hn - 1))];
         if (t + 1024 < nh) hv1 = a.H1[(base + topk_of((t + 1024) >> hsh)) * H + h0 + (t & (hn - 1))];
@@ -1419,8 +1422,8 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
 #pragma unroll
                 for (int sw = 0; sw < 2; ++sw) {
                     const int d = dl + sw * dcols;
-                    if (own && d < D) {
-                        const int e = (h_lo + hh * 2 + j) * D + d;
+                    if (own && d < D && j < JN) {
+                        const int e = (h_lo + hh * JN + j) * D + d;
                         pw[j][sw] = g.W1[e]; pm[j][sw] = g.m_W1[e]; pv[j][sw] = g.v_W1[e];
                     }
                 }
@@ -1511,7 +1514,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
     __syncthreads();
     MOC_STAMP(16);
     {   // dh[p][h] = (sum_i dz[p][i] * W2[i][h]) * [H1 > 0]  for this workgroup's columns
-        const int hn = wg == 0 ? H : 4, h0 = wg == 0 ? 0 : h_lo;
+        const int hn = wg == 0 ? H : HW, h0 = wg == 0 ? 0 : h_lo;
         for (int e = t; e < P * hn; e += 1024) {
             const int p = e / hn, h = h0 + (e - p * hn);
             float v = 0.f;
@@ -1522,8 +1525,8 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
     }
     __syncthreads();
     MOC_STAMP(17);
-    // ---- gradients of the owned elements: 2x2 of W1 per thread, one of b1 / W2 / b2 in workgroup 0
-    const int ha = h_lo + hh * 2;
+    // ---- gradients of the owned elements: JN x 2 of W1 per thread, one of b1 / W2 / b2 in workgroup 0
+    const int ha = h_lo + hh * JN;
     float gr[2][2] = {{0.f, 0.f}, {0.f, 0.f}};           // [d sweep][h sub-index]
     if (own) {
 #pragma unroll
@@ -1534,7 +1537,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
                 for (int p = 0; p < P; ++p) {
                     const float xv = xs[(size_t)p * D + d];
                     g0 = fmaf(dhs[p * H + ha], xv, g0);
-                    g1 = fmaf(dhs[p * H + ha + 1], xv, g1);
+                    if (JN > 1) g1 = fmaf(dhs[p * H + ha + 1], xv, g1);
                 }
                 gr[sw][0] = g0; gr[sw][1] = g1;
             }
@@ -1562,7 +1565,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
         if (own)
             for (int sw = 0; sw < 2; ++sw) {
                 const int d = dl + sw * dcols;
-                if (d < D) { g.g_W1[(ha + 0) * D + d] = gr[sw][0]; g.g_W1[(ha + 1) * D + d] = gr[sw][1]; }
+                if (d < D) { g.g_W1[(ha + 0) * D + d] = gr[sw][0]; if (JN > 1) g.g_W1[(ha + 1) * D + d] = gr[sw][1]; }
             }
         if (tail >= H + 4 * H) a.g_b2[tail - 5 * H] = gt;
         else if (tail >= H) a.g_W2[tail - H] = gt;
@@ -1576,7 +1579,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
 #pragma unroll
             for (int sw = 0; sw < 2; ++sw) {
                 const int d = dl + sw * dcols;
-                if (d < D) { p2p_push(g.x, (int64_t)(ha + 0) * D + d, gr[sw][0]); p2p_push(g.x, (int64_t)(ha + 1) * D + d, gr[sw][1]); }
+                if (d < D) { p2p_push(g.x, (int64_t)(ha + 0) * D + d, gr[sw][0]); if (JN > 1) p2p_push(g.x, (int64_t)(ha + 1) * D + d, gr[sw][1]); }
             }
         if (tail >= 0) p2p_push(g.x, nW1 + tail, gt);
         if (!p2p_signal_wait(g.x, wg, &p2p_ok)) return;   // time-out: reported through g.x.error, no update
@@ -1586,7 +1589,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
                 const int d = dl + sw * dcols;
                 if (d < D) {
                     gr[sw][0] = p2p_sum(g.x, (int64_t)(ha + 0) * D + d, gr[sw][0]);
-                    gr[sw][1] = p2p_sum(g.x, (int64_t)(ha + 1) * D + d, gr[sw][1]);
+                    if (JN > 1) gr[sw][1] = p2p_sum(g.x, (int64_t)(ha + 1) * D + d, gr[sw][1]);
                 }
             }
         if (tail >= 0) gt = p2p_sum(g.x, nW1 + tail, gt);
@@ -1600,6 +1603,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
             if (d < D) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
+                    if (j >= JN) continue;
                     const int e = (ha + j) * D + d;
                     adam_update(pw[j][sw], pm[j][sw], pv[j][sw], gr[sw][j] * gs, ak);
                     g.W1[e] = pw[j][sw]; g.m_W1[e] = pm[j][sw]; g.v_W1[e] = pv[j][sw];
@@ -2308,7 +2312,8 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
             MOC_FAIL(MOC_ELAUNCH, "moc_fused_step: cannot raise the dynamic LDS limit to %d bytes", FS_MAX_DYN_LDS);
         attr_set = true;
     }
-    pool_w1_step_kernel<<<H / 4, 1024, smem, s>>>(g, ws->pooled, ws->topk_idx, ws->topk_cnt, cap);
+    // 32 workgroups of two hidden units each, unless the gradient is exchanged inside the kernel (16 channels)
+    pool_w1_step_kernel<<<g.x.world > 1 ? H / 4 : H / 2, 1024, smem, s>>>(g, ws->pooled, ws->topk_idx, ws->topk_cnt, cap);
     MOC_CHECK_LAUNCH("moc_fused_step");
     return MOC_OK;
 }
