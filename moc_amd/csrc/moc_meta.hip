@@ -1678,7 +1678,9 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
         }
     }
     const AdamCoef ak = step_coef(a);
-    if (t < 4 * H) W2s[t] = a.W2[t];
+    // (W2 through a register: stored to LDS below, once the pooling's own first loads are under way -- a store here would
+    // wait for everything requested above before the slide's data is even asked for)
+    const float w2r = t < 4 * H ? a.W2[t] : 0.f;
     // small tensors: threads 0..15 -> W2[i][4 wg + jj] (i = t >> 2, jj = t & 3); 16..19 -> b1[4 wg + jj]; 20..23 -> b2 (wg 0)
     float pS = 0.f, pSm = 0.f, pSv = 0.f;
     int small = -1;                                       // flat tail index (b1 | W2 | b2), as in the narrow kernel
@@ -1706,10 +1708,14 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
         const PoolLds L = {list, wmax, pooled_s, dpool, ncand, topk_s};
         k = pool_phase<8, 32, 2>(a, b, L, PS_CAP, wg == 0, pooled_out, topk_idx_out, topk_cnt_out, &base);
     }
+    if (t < 4 * H) W2s[t] = w2r;
     __syncthreads();
     MOC_STAMP(41);
     // ---- pairs
     const int P = C * k;
+    // pairs per class k <= 16, pair numbers < 1024: p / k = (p * ceil(2^16 / k)) >> 16 exactly (no integer division: with
+    // sixteen waves on the CU the five of them per thread below were half of this phase)
+    const unsigned kinv = k > 0 ? (65536u + (unsigned)k - 1u) / (unsigned)k : 0u;
     for (int p = t; p < 2 * P; p += 1024) mask[p] = 0u;
     // the pairs' hidden rows are requested here, with the pair operands (both hang on topk_s only): their ReLU bits
     // are ORed into the masks after the barrier below
@@ -1719,12 +1725,12 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
         const int e = t + q * 1024;
         hv_pre[q] = float4{0.f, 0.f, 0.f, 0.f};
         if (e < P * 16) {
-            const int p = e >> 4, c = p / k;
+            const int p = e >> 4, c = (int)(((unsigned)p * kinv) >> 16);
             hv_pre[q] = *reinterpret_cast<const float4*>(a.H1 + (base + topk_s[c * K + (p - c * k)]) * H + (e & 15) * 4);
         }
     }
     for (int p = t; p < P; p += 1024) {
-        const int c = p / k, sidx = topk_s[c * K + (p - c * k)];
+        const int c = (int)(((unsigned)p * kinv) >> 16), sidx = topk_s[c * K + (p - c * k)];
         sidx_s[p] = sidx;
         prow_s[p] = a.sel_row[base + sidx];
         const float* cd = a.cand + base + sidx;
@@ -1785,7 +1791,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
                             const float4 z = *reinterpret_cast<const float4*>(dz + (c0 + pp) * 4);
                             v = fmaf(z.w, w3, fmaf(z.z, w2, fmaf(z.y, w1, z.x * w0)));
                         }
-                        dh_s[pp * 64 + h] = v;
+                        dh_s[pp * 64 + (h ^ ((pp & 3) << 4))] = v;      // (columns swizzled by the pair: the A-fragment reads below hit 64 banks)
                     }
                 }
             }
@@ -1809,7 +1815,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const int pp = ks + 4 * u + kq;
-                            av[u] = dh_s[pp * 64 + h0 + li];
+                            av[u] = dh_s[pp * 64 + ((h0 + li) ^ (kq << 4))];       // pp & 3 == kq (ks is a multiple of 4)
                             bv[u] = pp < n ? xval(pp) : 0.f;
                         }
 #pragma unroll
@@ -1817,7 +1823,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
                     }
                     for (; ks < n4; ks += 4) {
                         const int pp = ks + kq;
-                        gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(dh_s[pp * 64 + h0 + li], pp < n ? xval(pp) : 0.f, gacc, 0, 0, 0);
+                        gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(dh_s[pp * 64 + ((h0 + li) ^ (kq << 4))], pp < n ? xval(pp) : 0.f, gacc, 0, 0, 0);
                     }
                 };
                 if (a.xdt == MOC_F32) product(std::integral_constant<int, 0>{});

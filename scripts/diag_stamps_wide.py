@@ -11,10 +11,11 @@ torch.set_num_threads(8)
 from moc_amd import engine, main_moc as M, synth
 from moc_amd._lib import lib
 dev = torch.device("cuda:0")
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
 Cc, D, j, K, n = 30, 512, 400, 10, 30
 W, We = synth.make_bank(1234, D, Cc)
 M.set_classifier_bank(W.to(dev), We.to(dev))
-bags = [synth.make_bag_device(1234 + i, 15000, D, We, Cc, i % Cc, dev, torch.bfloat16) for i in range(n)]
+bags = [synth.make_bag_device(1234 + i, 15000, D, We, Cc, i % Cc, dev, DT) for i in range(n)]
 res = M.ResidentBags(bags, [i % Cc for i in range(n)], dev)
 torch.manual_seed(0)
 model = M.senet(D, 4).to(dev); opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
