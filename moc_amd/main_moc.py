@@ -452,9 +452,14 @@ def _binary_auc(pos: np.ndarray, score: np.ndarray) -> float:
     order = np.argsort(score, kind="mergesort")
     s = score[order]
     # mid-rank of every tie group: first occurrence index + (group size - 1) / 2, 1-based
-    start = np.r_[True, s[1:] != s[:-1]]
+    # (plain array writes, not np.r_: its index-trick machinery is 25 us a call, a third of this function)
+    start = np.empty(s.size, dtype=bool)
+    start[0] = True
+    np.not_equal(s[1:], s[:-1], out=start[1:])
     first = np.flatnonzero(start)
-    size = np.diff(np.r_[first, s.size])
+    size = np.empty(first.size, dtype=np.int64)
+    size[:-1] = first[1:] - first[:-1]
+    size[-1] = s.size - first[-1]
     mid = np.repeat(first + (size - 1) / 2.0 + 1.0, size)
     n_pos = int(pos.sum())
     n_neg = pos.size - n_pos
