@@ -169,12 +169,14 @@ def measured_traffic(kname, avg_bytes):
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         src = hashlib.sha256(open(os.path.join(ROOT, "moc_amd", "csrc", "moc_scores.hip"), "rb").read()).hexdigest()[:16]
-        if tj.get("kernel") != kname or tj.get("scores_src_sha16") != src:
-            return None
-        if abs(tj.get("algorithmic_bytes_per_launch", 0) - avg_bytes) > 0.01 * avg_bytes:
-            return None
-        return {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / "
-                "WRITE_SIZE, separate passes, same kernel source and launch size)", "captured_at": tj.get("git_head")}
+        for e in tj.get("entries", [tj]):             # one entry per captured launch size (the persistent grid is the same for all)
+            if e.get("kernel") != kname or e.get("scores_src_sha16") != src:
+                continue
+            if abs(e.get("algorithmic_bytes_per_launch", 0) - avg_bytes) > 0.01 * avg_bytes:
+                continue
+            return {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                    "WRITE_SIZE, separate passes, same kernel source and launch size)", "captured_at": e.get("git_head")}
+        return None
     except (OSError, ValueError, KeyError):
         return None
 

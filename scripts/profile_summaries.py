@@ -104,6 +104,19 @@ if traffic_kernel:
            "hbm_bytes_per_launch": v["fetch_bytes"] + v["write_bytes"], "fetch_bytes_corrected_x2": v["fetch_bytes"], "write_bytes": v["write_bytes"],
            "ratio_to_algorithmic": (round((v["fetch_bytes"] + v["write_bytes"]) / roof["algorithmic_bytes_per_launch"], 4) if roof.get("algorithmic_bytes_per_launch") else None),
            "grid": n.split("grid=")[1], "note": "medians over the capture's launches of that grid; FETCH_SIZE KiB x1024 x2 (gfx950 correction), WRITE_SIZE KiB x1024"}
-    json.dump(out, open(os.path.join(root, "profiles", "traffic.json" if "--as-default" in sys.argv else f"{tag}_traffic.json"), "w"), indent=1)
+    if "--as-default" in sys.argv:
+        # profiles/traffic.json holds one entry per (kernel, launch size): this capture replaces its own, keeps the others
+        path = os.path.join(root, "profiles", "traffic.json")
+        try:
+            old = json.load(open(path))
+            entries = old.get("entries", [old])
+        except (OSError, ValueError):
+            entries = []
+        same = lambda e: (e.get("kernel") == out["kernel"] and out["algorithmic_bytes_per_launch"] and e.get("algorithmic_bytes_per_launch") and
+                          abs(e["algorithmic_bytes_per_launch"] - out["algorithmic_bytes_per_launch"]) <= 0.01 * out["algorithmic_bytes_per_launch"])
+        entries = [e for e in entries if not same(e)] + [out]
+        json.dump({"entries": entries}, open(path, "w"), indent=1)
+    else:
+        json.dump(out, open(os.path.join(root, "profiles", f"{tag}_traffic.json"), "w"), indent=1)
     print(json.dumps(out))
 print("ok", tag)
