@@ -325,7 +325,7 @@ def _resident_pass_setup(res, device, args):
     ahead, plan["ahead"] = plan["ahead"], None
     if ahead is not None and ahead["bank"] is bank and ahead["after"] is not None and torch.equal(ahead["before"], now):
         torch.set_rng_state(ahead["after"])             # the draws happened: put the generator where they leave it
-        torch.cuda.current_stream().wait_event(ahead["done"])
+        ahead["done"].wait()                            # (the current stream waits; no Stream object is built)
         plan["turn"] = ahead["turn"]
     else:
         if ahead is not None:
@@ -367,12 +367,11 @@ def resident_pass_done(res, device, args):
         return
     bank = _bank_for(res.X, device)
     plan = res.train_plan(bank.C, bank.Ce, args.topj, args.topk, args.discard_classifiers)
-    main = torch.cuda.current_stream()
     # a set of arrays is free again when the meta-steps that read it have run: mark this pass's end on `main`;
     # the other set was last read by the PREVIOUS pass's meta-steps (their mark was left one call ago), so the
     # side stream waits for that one only and phase A of the next pass overlaps THIS pass's meta-steps
     mark = torch.cuda.Event()
-    mark.record(main)
+    mark.record()                                       # (on the current stream -- `main` below)
     plan.setdefault("steps_done", [None, None])[plan["turn"]] = mark
     nplan = _next_plan(res, plan, bank, args)
     if nplan is None:

@@ -651,12 +651,14 @@ def test_batched_forward_is_bit_identical_to_one_slide_at_a_time(dev, dtype, D, 
         assert torch.equal(together["gates"][o:o + n], t["gates"][o:o + n])
 
 
-@pytest.mark.parametrize("D,C,j", [(512, 2, 400), (256, 3, 150), (768, 5, 90), (1024, 30, 40), (512, 64, 20)])
-def test_fp32_forward_split_over_four_wave_groups_gives_the_four_wave_bits(dev, D, C, j):
+@pytest.mark.parametrize("D,C,j,for_eval", [(512, 2, 400, False), (256, 3, 150, False), (768, 5, 90, False), (1024, 30, 40, False),
+                                            (512, 64, 20, False), (512, 30, 60, True), (256, 6, 100, True)])
+def test_fp32_forward_split_over_four_wave_groups_gives_the_four_wave_bits(dev, D, C, j, for_eval):
     """fp32 bags: the one-slide forward of the training step splits the columns over four wave groups (sixteen waves, every
     row requested whole at once); with MOC_FORWARD_FOUR_WAVES it is the four-wave kernel, one chain per wave over all the
     columns, folded into the same ((p0 + p1) + p2) + p3: hidden layer, gates and mixed scores bit for bit, one slide at a
-    time and several per launch, short last tiles included."""
+    time and several per launch, short last tiles included; for_eval: the variant that reads the candidate scores from the
+    score pass's statistics (MOC_CAND_FROM_STATS)."""
     M, E = _mm(), _engine()
     from moc_amd import _lib
     K = 10
@@ -667,7 +669,8 @@ def test_fp32_forward_split_over_four_wave_groups_gives_the_four_wave_bits(dev, 
     model = M.senet(D, 4).to(dev)
     X, _ = M._pack(bags, dev, torch.float32)
     b = E.SlideBatch(X, sizes, C, C + 4, j, K)
-    b.phase_a(E.Bank.get(W.to(dev), We.to(dev), torch.float32, dev))
+    b.phase_a(E.Bank.get(W.to(dev), We.to(dev), torch.float32, dev), for_eval=for_eval)
+    assert bool(b.c.flags & _lib.MOC_CAND_FROM_STATS) == for_eval       # (evaluation of a wide bank: candidate scores read from the statistics)
     meta = E.MetaState(model)
     t = b.meta_ws()[0]
     out = {}
