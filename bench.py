@@ -475,8 +475,13 @@ def main():
         # the kernel moc_scores launches for this shape (moc_scores.hip), as rocprofv3 names it
         nt = (C + 4 + 15) // 16
         half, f16 = ("true", "true" if a.dtype == "fp16" else "false") if esz == 2 else ("false", "false")
+        ticketed = False
         if nt <= (3 if esz == 2 else 4):
-            kname = f"scores_stream_kernel<{16 if (D * esz) % 1024 == 0 else 8}, {half}, {nt}, {f16}>"
+            # (the look-ahead launches of a train pass take the ticketed form and stay off MOC_RESERVE_CUS compute units,
+            # engine.RESERVE_CUS; four n-tiles keep the static walk)
+            ticketed = engine.RESERVE_CUS > 0 and M.PREFETCH_PHASE_A and nt < 4
+            kname = (f"scores_stream_kernel<{16 if (D * esz) % 1024 == 0 else 8}, {half}, {nt}, {f16}, "
+                     f"{'true' if ticketed else 'false'}>")
         elif esz == 2 and nt <= 8 and D % 64 == 0:
             kname = f"scores_wide_ring_kernel<{nt}, {f16}>" if nt <= 5 else f"scores_wide_kernel<{nt}, {f16}>"
         else:
@@ -485,6 +490,11 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
                 "launches": len(ms)}
+        if ticketed:
+            roof["placement"] = {"compute_units_left_to_the_meta_steps": engine.RESERVE_CUS, "tiles": "by ticket",
+                                 "note": "the timed launches run beside the previous pass's meta-steps and stay off that many "
+                                         "of the 256 compute units (include/moc_hip.h); `whole_chip` is the same kernel as an "
+                                         "evaluation pass launches it: every compute unit, static walk, nothing beside it"}
         # The statistics the pass must write -- (2C + 3) floats and a flag byte per kept row -- are not in SURVEY.md's
         # algorithmic figure (reads of the bag: 8d); they are 3 % of the bytes at two classes and 25 % at thirty, and at
         # that ratio HBM serves reads at 4.1-4.2 TB/s whatever the shape of the stores (profiles/round2_store_shape_bench.txt)
@@ -512,6 +522,20 @@ def main():
         roof["alone"] = {"achieved": round(iso_bytes / (iso_ms * 1e-3) / 1e9, 1),
                          "frac": round(iso_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launch_us": round(iso_ms * 1e3, 2),
                          "algorithmic_bytes": int(iso_bytes)}
+        if ticketed and last.c.tile_ticket is not None:
+            keep = (last.c.tile_ticket, last.c.cu_reserved)
+            last.c.tile_ticket, last.c.cu_reserved = None, None
+            try:
+                iso = []
+                for _ in range(10):
+                    e0, e1 = engine.timed_scores(last, M._bank_for(Xl, dev))
+                    torch.cuda.synchronize()
+                    iso.append(e0.elapsed_time(e1))
+            finally:
+                last.c.tile_ticket, last.c.cu_reserved = keep
+            w_ms = sorted(iso)[len(iso) // 2]
+            roof["whole_chip"] = {"kernel": kname.replace(", true>", ", false>"), "achieved": round(iso_bytes / (w_ms * 1e-3) / 1e9, 1),
+                                  "frac": round(iso_bytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launch_us": round(w_ms * 1e3, 2)}
 
     # ---- the same loop on 16-bit copies of the bags (N = 1, default fp32 run): BASELINE configs[1] names bf16 storage,
     # but the trained AUC does not stay within +-0.002 of the fp32 reference there, so it is an extra block, not `value`

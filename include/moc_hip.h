@@ -39,7 +39,10 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 14
+#define MOC_ABI_VERSION 15
+
+enum { MOC_TICKET_QUEUES = 64, MOC_TICKET_STRIDE = 64,     /* moc_batch_t.tile_ticket: counters, int32 words between them */
+       MOC_TICKET_WORDS = (64 + 8) * 64 };
 
 enum { MOC_OK = 0, MOC_EINVAL = 1, MOC_EUNSUPPORTED = 2, MOC_ELAUNCH = 3 };
 
@@ -118,6 +121,9 @@ typedef struct moc_batch {
     int64_t* sel_row;    /* [total_rows]      same positions: row of X (packed) to gather             */
     int32_t* n_sel;      /* [n_slides]        S                                                       */
     float*   cand;       /* [2C+2, total_rows] per selected row: s_p[C] | s_sigma[C] | s_delta | s_beta */
+    /* ---- placement of the score pass (round 3; both nullable = static walk over the whole chip) ---- */
+    const uint32_t* cu_reserved; /* device [128]: compute units the score pass stays off (see moc_cu_census)   */
+    int32_t*        tile_ticket; /* device [MOC_TICKET_WORDS]: the score pass's tile counters                  */
 } moc_batch_t;
 
 /* The meta-learner ("senet", main_moc.py:299-312) and its Adam state
@@ -372,6 +378,26 @@ int moc_step_graph_destroy(moc_step_graph_t* G);
 int moc_step_graph_stats(const moc_step_graph_t* G, int* captures, int* replays, int* eager_calls);
 int moc_train_steps_graph(moc_step_graph_t* G, const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
                           const int64_t* labels, int slide0, int n, uint32_t use_bits, moc_stream_t stream);
+
+/* ---- compute units kept free of the score pass (round 3) -----------------------------------------------------------
+ * Phase A of the NEXT pass (main_moc.py:322-375 for every slide: no trainable parameter) is issued a pass ahead on a
+ * side stream while the sequential meta-steps of this pass (main_moc.py:380-410) run.  The score pass fills every CU
+ * with persistent workgroups, and a 16-wave meta-step workgroup fits on no CU that holds one of them: the meta-steps
+ * stalled for the length of the score pass.  (Confining the side stream's queue with a CU mask,
+ * hipExtStreamCreateWithCUMask, was measured: the masked queue is not scheduled beside the unmasked one at all -- the
+ * rate halves; profiles/NOTES.md.)  Instead the score pass itself stays off a set of compute units:
+ *   moc_batch_t.tile_ticket  (device int32[MOC_TICKET_WORDS], nullable): the score pass hands out its 16-row tiles
+ *       through MOC_TICKET_QUEUES counters (eight per XCD, 256 bytes apart, two tiles per ticket; a wave whose own has
+ *       run out takes from any other; eight more words rank the workgroups of each XCD) instead of a static stride per
+ *       wave, so any number of its workgroups can do all the work (moc_scores zeroes them in stream order before each
+ *       launch);
+ *   moc_batch_t.cu_reserved  (device uint32[128], nullable; needs tile_ticket): bit (xcc * 256 + HW_ID[15:8]) set = a
+ *       workgroup of the score pass that finds itself on that compute unit ends at once (the first eight workgroups of
+ *       a launch never do: progress does not depend on the table being right).
+ * moc_cu_census finds out which (xcc, HW_ID[15:8]) slots the device has: it launches `n_wg` one-wave workgroups that
+ * each hold their CU for ~`hold_us` microseconds and counts them in hist[xcc * 256 + HW_ID[15:8]] (device int32
+ * [16 * 256], zeroed by the caller).  The host picks the reserved slots from it (moc_amd/engine.py: reserved_cus). */
+int moc_cu_census(int32_t* hist, int n_wg, int hold_us, moc_stream_t stream);
 
 /* ---- generic pooling / ranking (a12, a17 and the index_* helpers) ----------
  * For each segment s (rows seg_off[s] .. seg_off[s+1]) and class c: rank rows by

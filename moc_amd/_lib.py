@@ -15,9 +15,10 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 MOC_F32, MOC_BF16, MOC_F16 = 0, 1, 2
+TICKET_WORDS = (64 + 8) * 64    # MOC_TICKET_WORDS (moc_batch_t.tile_ticket)
 MOC_STATS_COMPACT = 1
 MOC_SELECT_PER_COLUMN = 2
 MOC_CAND_FROM_STATS = 4
@@ -36,6 +37,7 @@ class MocBatch(C.Structure):
         ("discard_bits", C.c_uint32), ("flags", C.c_uint32),
         ("kept", _p), ("n_kept", _p), ("stats", _p), ("sel_flag", _p), ("sel_idx", _p),
         ("sel_row", _p), ("n_sel", _p), ("cand", _p),
+        ("cu_reserved", _p), ("tile_ticket", _p),
     ]
 
 
@@ -102,6 +104,7 @@ SIGNATURES = {
     "moc_gated_attention_dab_stride": (C.c_int, [C.c_int, C.c_int]),
     "moc_gated_attention_backward": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p, _p, _p, C.c_int, _p, C.c_int, _p, _p, _p,
                                                _p, _p, _p, _p, _p, C.c_size_t, _p]),
+    "moc_cu_census": (C.c_int, [_p, C.c_int, C.c_int, _p]),
     "moc_topk_mean": (C.c_int, [_p, C.c_int64, _p, C.c_int64, _p, _p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, _p, _p, _p, _p]),
 }

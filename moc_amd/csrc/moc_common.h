@@ -19,6 +19,8 @@ static __device__ __forceinline__ float moc_fmul(float a, float b) { return a * 
 static __device__ __forceinline__ float moc_fdiv(float a, float b) { return a / b; }
 static __device__ __forceinline__ float moc_fsqrt(float a) { return __builtin_sqrtf(a); }
 
+// streaming score pass, ticketed walk: tiles per ticket (moc_scores.hip)
+#define MOC_TILES_PER_TICKET 2
 #define MOC_WAVE 64
 #define MOC_HIDDEN 64
 

@@ -125,6 +125,8 @@ struct ScoresArgs {
     int tpw;                 // 16-row tiles per wave (1 when NT > 1)
     float oscale;            // products -> logits: 1, or 2^-14 for the scaled fp16 image
     int compact;             // MOC_STATS_COMPACT: logits[C] | m1 | 1/den | gap | bg_sum | bg_max (no softmax columns)
+    const uint32_t* cu_reserved;   // nullable: compute units the streaming form stays off (moc_batch_t.cu_reserved)
+    int32_t* ticket;               // nullable: the streaming form's tile counter (moc_batch_t.tile_ticket), zero at launch
 };
 
 // one lane per row: reads the 16 x Ctp tile the wave just wrote, emits the statistics
@@ -498,11 +500,37 @@ __device__ __forceinline__ void compute_pairs_impl(const u32x4_t (&buf)[NF], u32
 #define MOC_PHASE(id) do { } while (0)
 #define MOC_PHASE_END() do { } while (0)
 #endif
-template <int NF, bool BF16, int NT, bool F16 = false>
+template <int NF, bool BF16, int NT, bool F16 = false, bool DYN = false>
 __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(ScoresArgs a, int slide0, int n_slides) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ESZ = BF16 ? 2 : 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // compute units left to the meta-steps of the pass in progress (include/moc_hip.h): a workgroup that finds itself on
+    // one ends here, before it has touched anything; the tiles are handed out by ticket, so whoever stays does all the
+    // work.  The first eight workgroups stay wherever they are: progress does not hang on the table.
+    if (a.cu_reserved != nullptr && blockIdx.x >= 8) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const uint32_t slot = (xcc & 15u) * 256u + ((hw >> 8) & 255u);
+        if ((a.cu_reserved[slot >> 5] >> (slot & 31u)) & 1u) return;          // (uniform: a workgroup lives on one CU)
+    }
+    // ticketed walk: which of its XCD's counters this workgroup draws from -- by its rank among the workgroups of the XCD
+    // that STAY (one atomic per workgroup, answered while the image is staged), so that the counters of an XCD have the
+    // same number of workgroups whatever the placement did (by blockIdx, a reserved set of 72 CUs left some counters
+    // with no workgroup at all: their tiles went through the slow sweep, 158 instead of 120 us)
+    // (in the launch's dynamic LDS, behind the per-slide metadata: the 16 bytes of slack the launcher adds)
+    int& s_counter = *(reinterpret_cast<int*>(smem + (size_t)NT * (BF16 ? (a.D / 32) * 3 * 1024 : (a.D / 16) * 1024) +
+                                                  4 * 16 * (NT * 16 + 1) * sizeof(float)) + 6 * n_slides + 1);
+    if constexpr (DYN) {
+        if (threadIdx.x == 0) {
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const int x = (int)(xcc & 7u);
+            const int r = atomicAdd(a.ticket + (MOC_TICKET_QUEUES + x) * MOC_TICKET_STRIDE, 1);
+            s_counter = x * (MOC_TICKET_QUEUES / 8) + r % (MOC_TICKET_QUEUES / 8);
+        }
+    }
     const int64_t row_bytes = (int64_t)a.D * ESZ;
     const int U = (int)(row_bytes / (NF * 64));                  // units per tile
     const int img_bytes = BF16 ? (a.D / 32) * 3 * 1024 : (a.D / 16) * 1024;
@@ -663,26 +691,145 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
     // the next unit's loads (vmcnt is in order; at the loop back edge hipcc assumes the worst).
     // Instead: issue the NF loads of the next unit, then wait until only those NF are outstanding
     // -- everything older (the current unit's loads, the previous epilogue's stores) has landed.
-    int g = blockIdx.x * 4 + wave, ch = 0;
-    auto advance = [&]() { if (++ch == U) { ch = 0; g += stride; } };
+    // Tiles by ticket (DYN) or by a static stride per wave.  Tickets: MOC_TICKET_QUEUES counters, 256 bytes apart; counter
+    // q hands out the tiles t * Q + q (t = 0, 1, ...).  A wave draws from the counter of its own XCD in the pipelined
+    // loop; when that has run out it leaves the loop and takes what any OTHER counter still holds, one tile at a time
+    // (the sweep behind the loop: slow, and idle unless an XCD has no workgroup of this launch left) -- so every tile is
+    // handed out whatever workgroups exist and wherever they sit.  (ONE counter serialised the whole launch: a returning
+    // atomic on one address takes ~16 ns on this part, 15,000 tiles x 16 ns = 2.3x the kernel's own time.)  A wave's
+    // state: `g` the tile whose loads are being issued, `g_next` the one after it (known), and tickets in flight.  A
+    // request is an atomic with return issued by hand (lane 0 only, exec switched inside the asm) so that the compiler's
+    // wait insertion does not see it.
+    // (DYN is a template parameter, not a branch: a join of the two walks behind the request made the compiler copy the
+    // ticket register while the value was still in flight.)
+    constexpr bool dyn = DYN;
+    constexpr int NQ = MOC_TICKET_QUEUES, QS = MOC_TICKET_STRIDE;
+    static_assert(NQ % 8 == 0 && NQ <= 64, "one ballot over the counters");
+    constexpr int DONE = 0x7fffffff;
+    int g, g_next = 0, ch = 0;
+    int q = 0;                                                    // this wave's counter: its XCD's
+    // vmcnt retires IN ORDER, so where the request sits among the loads decides who waits for it.  Every unit issues
+    // exactly one ticket operation right BEFORE its NF loads -- the request itself at a tile boundary, a dummy 4-byte load
+    // otherwise -- so that every counted wait is vmcnt(NF + 1): it retires the previous unit's loads and the ticket
+    // operation before THEM, never the one just issued.  A request made in unit j has therefore landed after unit
+    // j + 1's wait and is taken up in unit j + 2 at the earliest: the two halves of the two-buffer loop below each own a
+    // ticket register (pend1 / pend2), requested and taken up at that half's tile boundaries.  Rows of 2 or 4 units:
+    // all boundaries fall into the second half; 1 or 3 units: they alternate.
+    unsigned pend1 = 0, pend2 = 0, dummy1 = 0, dummy2 = 0;
+    // a ticket is TPT consecutive slots of its counter; slot t of counter q is tile t * NQ + q
+    constexpr int TPT = MOC_TILES_PER_TICKET;
+    static_assert(TPT % 2 == 0, "tickets are taken up at every TPT-th tile boundary: always in the same half of the loop");
+    int base = 0, sub = 0;
+    const unsigned tpt_inc = (unsigned)TPT;
+    auto opaque_vgpr = [](int uniform) { int v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(uniform)); return v; };
+    // ("+v": a ticket lives in ONE register across the loop -- with a fresh output register the compiler copied it into the
+    // loop-carried one right behind the request, i.e. before the value had arrived: tests/test_isa_hazards_cpu.py)
+    // one asm statement for both kinds (the branch is INSIDE it): with `if (boundary) request(pend) else dummy(d)` in C++
+    // the compiler merged the two behind a pointer select and kept the registers in scratch memory -- stored right
+    // behind the request, i.e. before the value had arrived
+    auto ticket_op = [&](unsigned& pend, unsigned& d, bool boundary) {
+        unsigned long long sv;
+        asm volatile("s_mov_b64 %2, exec\n\t"
+                     "s_mov_b64 exec, 1\n\t"
+                     "s_cmp_lg_u32 %5, 0\n\t"
+                     "s_cbranch_scc0 1f\n\t"
+                     "global_atomic_add %0, %3, %4, off sc0\n\t"
+                     "s_branch 2f\n"
+                     "1:\n\t"
+                     "global_load_dword %1, %6, off\n"
+                     "2:\n\t"
+                     "s_mov_b64 exec, %2"
+                     : "+v"(pend), "+v"(d), "=&s"(sv)
+                     : "v"(a.ticket + q * QS), "v"(tpt_inc), "s"(__builtin_amdgcn_readfirstlane((int)boundary)), "v"(a.bank) : "memory", "scc");
+    };
+    auto tile_of = [&](int t) -> int { return (t < (1 << 24) && t * NQ + q < total) ? t * NQ + q : DONE; };
+    if constexpr (dyn) {
+        q = __builtin_amdgcn_readfirstlane(s_counter);               // (NQ / 8 counters per XCD; written before the barriers above)
+        // the first two tickets in one request (compiler-managed wait: nothing else is in flight yet): the first one's
+        // tiles go to g and g_next, the second sits in the ticket register as if it had just landed (in both halves':
+        // only the half that takes tickets up -- the first for an odd number of units per tile, else the second --
+        // ever looks at its own)
+        int t0 = 0;
+        if (lane == 0) t0 = atomicAdd(a.ticket + q * QS, 2 * TPT);
+        t0 = __builtin_amdgcn_readfirstlane(t0);
+        // (the tickets are uniform, but the walk keeps them in VECTOR registers the compiler cannot see through, as the
+        // static walk's g = 4 * blockIdx + wave is: with scalar loop control the compiler rotates the two-buffer loop
+        // into one body plus register copies -- copies of load destinations still in flight)
+        g = opaque_vgpr(tile_of(t0));
+        g_next = opaque_vgpr(tile_of(t0 + 1));
+        base = t0;
+        sub = 1;
+        pend1 = pend2 = (unsigned)opaque_vgpr(t0 + TPT);
+    } else {
+        g = blockIdx.x * 4 + wave;
+    }
+    auto advance = [&](unsigned& pend, unsigned& dummy) {
+        const bool boundary = ++ch == U;
+        if (boundary) ch = 0;
+        if constexpr (dyn) {
+            bool req = false;
+            if (boundary) {
+                g = g_next;
+                if (sub + 1 < TPT) {                              // the ticket in hand has another tile
+                    ++sub;
+                } else {
+                    asm volatile("" : "+v"(pend));                // (landed: see above; no use may move above the last wait)
+                    base = __builtin_amdgcn_readfirstlane((int)pend);
+                    sub = 0;
+                    req = true;
+                }
+                g_next = opaque_vgpr(tile_of(base + sub));
+            }
+            ticket_op(pend, dummy, req);                          // (a request also past the end: one operation per unit)
+        } else {
+            if (boundary) g += stride;
+        }
+    };
+    constexpr int KEEP = NF + (DYN ? 1 : 0);                      // loads of the unit just issued (+ its ticket operation)
     u32x4_t bufA[NF], bufB[NF];
     Unit uA, uB;
     if (g < total) { locate(g, ch, uA); asm_issue<0, NF>(bufA, uA.p); }
     MOC_PHASE_BEGIN();
     while (g < total) {
-        advance();
+        advance(pend1, dummy1);
         const bool moreB = g < total;
-        if (moreB) { locate(g, ch, uB); MOC_PHASE(0); asm_issue<0, NF>(bufB, uB.p); MOC_PHASE(4); asm_wait_keep<NF, NF>(bufA); }
+        if (moreB) { locate(g, ch, uB); MOC_PHASE(0); asm_issue<0, NF>(bufB, uB.p); MOC_PHASE(4); asm_wait_keep<KEEP, NF>(bufA); }
         else asm_wait_keep<0, NF>(bufA);
         MOC_PHASE(1);
         compute(bufA, uA);
         if (!moreB) break;
-        advance();
+        advance(pend2, dummy2);
         const bool moreA = g < total;
-        if (moreA) { locate(g, ch, uA); MOC_PHASE(0); asm_issue<0, NF>(bufA, uA.p); MOC_PHASE(4); asm_wait_keep<NF, NF>(bufB); }
+        if (moreA) { locate(g, ch, uA); MOC_PHASE(0); asm_issue<0, NF>(bufA, uA.p); MOC_PHASE(4); asm_wait_keep<KEEP, NF>(bufB); }
         else asm_wait_keep<0, NF>(bufB);
         MOC_PHASE(1);
         compute(bufB, uB);
+    }
+    if constexpr (dyn) {
+        // ---- the sweep behind the loop: tiles other counters still hold (see above).  One at a time, nothing pipelined;
+        // counter values only grow, so a stale read can only make a counter look open that is not -- `dead` remembers those.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long dead = 1ull << q;
+        for (;;) {
+            int v = 1 << 24;
+            if (lane < NQ) v = __hip_atomic_load(a.ticket + lane * QS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool open = lane < NQ && !((dead >> lane) & 1ull) && v < (1 << 24) && v * NQ + lane < total;
+            const unsigned long long m = __ballot(open);
+            if (m == 0) break;
+            const int qq = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+            int t = 0;
+            if (lane == 0) t = atomicAdd(a.ticket + qq * QS, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (!(t < (1 << 24) && t * NQ + qq < total)) { dead |= 1ull << qq; continue; }
+            const int gs = opaque_vgpr(t * NQ + qq);
+            cb = -1;
+            for (int c2 = 0; c2 < U; ++c2) {
+                locate(gs, c2, uA);
+                asm_issue<0, NF>(bufA, uA.p);
+                asm_wait_keep<0, NF>(bufA);
+                compute(bufA, uA);
+            }
+        }
     }
     MOC_PHASE_END();
 }
@@ -1056,6 +1203,20 @@ extern "C" int moc_mask_compact(const moc_batch_t* B, moc_stream_t stream) {
 // ev0 / ev1 (nullable): HIP events that take the score kernel's OWN start and end time stamps (hipExtLaunchKernel: the
 // dispatch's profiling stamps, not the moment a marker packet reaches the queue -- an event pair recorded around the
 // launch on a busy GPU measured 59 us for a kernel rocprofv3 times at 47).  A batch launched in chunks: first / last.
+// the ticketed form of the streaming kernel (up to three n-tiles; see scores_impl)
+template <int NF, bool BF, int NTT, bool FH>
+static void launch_stream_ticketed(const ScoresArgs& a, int wgs, size_t smem, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
+                                   int s0, int ns) {
+    if constexpr (NTT < 4) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)scores_stream_kernel<NF, BF, NTT, FH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipExtLaunchKernelGGL((scores_stream_kernel<NF, BF, NTT, FH, true>), dim3(wgs), dim3(256), smem, s, ev0, ev1, 0, a, s0, ns);
+    }
+}
+
 static int scores_impl(const moc_batch_t* B, const void* bank, moc_stream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (int rc = moc_check_batch(B, "moc_scores")) return rc;
     MOC_REQUIRE(bank && B->stats && B->sel_flag, "moc_scores: null bank/stats/sel_flag");
@@ -1071,6 +1232,8 @@ static int scores_impl(const moc_batch_t* B, const void* bank, moc_stream_t stre
     a.stride = B->total_rows;
     a.D = B->D; a.C = B->C; a.Ce = B->Ce; a.NT = bank_nt(B->Ce);
     a.compact = (B->flags & MOC_STATS_COMPACT) ? 1 : 0;
+    a.cu_reserved = nullptr;
+    a.ticket = nullptr;
     const bool bf = B->dtype != MOC_F32;          // 16-bit storage (bf16 or fp16): 3-term image, K = 32 per MFMA
     const bool f16 = B->dtype == MOC_F16;
     a.oscale = f16 ? 1.f / MOC_F16_BANK_SCALE : 1.f;
@@ -1104,8 +1267,11 @@ static int scores_impl(const moc_batch_t* B, const void* bank, moc_stream_t stre
                 (void)hipFuncSetAttribute((const void*)scores_stream_kernel<NF, BF, NTT, FH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                 attr_set = true;                                                                        \
             }                                                                                           \
-            hipExtLaunchKernelGGL((scores_stream_kernel<NF, BF, NTT, FH>), dim3(wgs), dim3(256), smem, s,  \
-                                  (s0 == 0 ? ev0 : nullptr), (s0 + ns == B->n_slides ? ev1 : nullptr), 0, a, s0, ns); \
+            if (a.ticket) launch_stream_ticketed<NF, BF, NTT, FH>(a, wgs, smem, s, (s0 == 0 ? ev0 : nullptr),       \
+                                                                   (s0 + ns == B->n_slides ? ev1 : nullptr), s0, ns); \
+            if (!a.ticket)                                                                                      \
+                hipExtLaunchKernelGGL((scores_stream_kernel<NF, BF, NTT, FH, false>), dim3(wgs), dim3(256), smem, s,  \
+                                      (s0 == 0 ? ev0 : nullptr), (s0 + ns == B->n_slides ? ev1 : nullptr), 0, a, s0, ns); \
         } while (0)
 #define MOC_LAUNCH_STREAM_NT(NF, BF, FH)                                                                \
         do {                                                                                            \
@@ -1113,8 +1279,16 @@ static int scores_impl(const moc_batch_t* B, const void* bank, moc_stream_t stre
             else if (a.NT == 2) MOC_LAUNCH_STREAM(NF, BF, 2, FH);                                       \
             else if (a.NT == 3) MOC_LAUNCH_STREAM(NF, BF, 3, FH);                                       \
         } while (0)
+        MOC_REQUIRE(B->cu_reserved == nullptr || B->tile_ticket != nullptr, "moc_scores: cu_reserved needs tile_ticket");
+        a.ticket = B->tile_ticket;
+        a.cu_reserved = B->cu_reserved;
+        // (four n-tiles, fp32 only: the ticketed form leaves the compiler short of registers and it re-uses load
+        // destinations still in flight -- tests/test_isa_hazards_cpu.py; that shape keeps the static walk, whole chip)
+        if (a.NT == 4) { a.ticket = nullptr; a.cu_reserved = nullptr; }
         for (int s0 = 0; s0 < B->n_slides; s0 += chunk) {
             const int ns = B->n_slides - s0 < chunk ? B->n_slides - s0 : chunk;
+            if (a.ticket && hipMemsetAsync(a.ticket, 0, sizeof(int32_t) * (MOC_TICKET_QUEUES + 8) * MOC_TICKET_STRIDE, s) != hipSuccess)
+                MOC_FAIL(MOC_ELAUNCH, "moc_scores: clearing the tile counter failed");
             if (row_b % 1024 == 0) {
                 if (f16) MOC_LAUNCH_STREAM_NT(16, true, true);
                 else if (bf) MOC_LAUNCH_STREAM_NT(16, true, false);

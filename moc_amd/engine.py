@@ -26,6 +26,13 @@ GRAPH_TABLE_STEPS = 4096        # Adam steps of coefficients kept on the device 
 CAND_FROM_STATS = os.environ.get("MOC_CAND_FROM_STATS", "1") != "0"   # evaluation: no materialised candidate columns (0: as in training)
 COMPACT_STATS = os.environ.get("MOC_COMPACT_STATS", "1") != "0"     # wide banks: C + 5 statistics per row (0: always 2C + 3)
 
+# The look-ahead phase A of a train pass stays off MOC_RESERVE_CUS compute units, which the sequential meta-steps of the
+# pass in progress then find free (moc_batch_t.cu_reserved + tile_ticket, include/moc_hip.h; 0: the whole chip, static
+# walk).  Measured on the default workload (scripts/sweep_reserve_cus.sh, profiles/NOTES.md): 0 -> 42.9 k, 48 -> 44.2 k,
+# 64 -> 45.6 k, 96 -> 42.9 k meta-steps/s; the ticketed walk alone costs the score pass 7 % (fp32) / 19 % (bf16), so
+# passes with nothing beside them (evaluation) keep the static walk.
+RESERVE_CUS = int(os.environ.get("MOC_RESERVE_CUS", "64"))
+
 # bench.py sets this to a list: every batched score-pass launch then appends
 # (start_event, stop_event, algorithmic_bytes) recorded on the launch stream.
 SCORE_EVENTS = None
@@ -41,6 +48,59 @@ def _stream():
     if _raw_stream is not None:
         return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_census = {}      # device index -> sorted list of (xcc, hw_id_bits) slots
+_reserved = {}    # (device index, n) -> device int32[128] bitmap
+
+
+def cu_slots(device):
+    """The compute units of `device` as (xcc, HW_ID[15:8]) slots, found by moc_cu_census (once per process)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _census:
+        with torch.cuda.device(idx):
+            hist = torch.zeros(16 * 256, dtype=torch.int32, device=dev)
+            check(lib().moc_cu_census(ptr(hist), 16384, 20, _stream()), "moc_cu_census")
+            h = hist.cpu().view(16, 256)
+        _census[idx] = sorted((x, s) for x in range(16) for s in range(256) if int(h[x, s]) > 0)
+    return _census[idx]
+
+
+def reserved_cus(device, n):
+    """Device bitmap (int32[128], bit xcc * 256 + HW_ID[15:8]) of `n` compute units the look-ahead score pass stays off:
+    an equal share of every XCD, dealt over its shader engines / arrays (highest CU id of each first).  None for n <= 0."""
+    n = int(n)
+    if n <= 0:
+        return None
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, n)
+    if key not in _reserved:
+        slots = cu_slots(dev)
+        assert n <= len(slots) // 2, f"MOC_RESERVE_CUS={n}: the device has {len(slots)} compute units"
+        xccs = sorted({x for x, _ in slots})
+        chosen = []
+        per = [n // len(xccs) + (1 if i < n % len(xccs) else 0) for i in range(len(xccs))]
+        for x, want in zip(xccs, per):
+            groups = {}
+            for _, s_ in (t for t in slots if t[0] == x):
+                groups.setdefault(s_ >> 4, []).append(s_)                # HW_ID[15:12] = SE | SH; [11:8] = CU
+            order = [sorted(g, reverse=True) for _, g in sorted(groups.items())]
+            k = 0
+            while want > 0:
+                g = order[k % len(order)]
+                if g:
+                    chosen.append((x, g.pop(0)))
+                    want -= 1
+                k += 1
+        words = [0] * 128
+        for x, s_ in chosen:
+            bit = x * 256 + s_
+            words[bit >> 5] |= 1 << (bit & 31)
+        t = torch.tensor([w - (1 << 32) if w >= (1 << 31) else w for w in words], dtype=torch.int32)
+        _reserved[key] = t.to(dev)
+    return _reserved[key]
 
 
 def timed_scores(batch, bank):
@@ -151,7 +211,22 @@ class SlideBatch:
             topk=self.topk, discard_bits=self.discard_bits, flags=0, kept=ptr(self.kept),
             n_kept=ptr(self.n_kept), stats=ptr(self.stats), sel_flag=ptr(self.sel_flag),
             sel_idx=ptr(self.sel_idx), sel_row=ptr(self.sel_row), n_sel=ptr(self.n_sel), cand=ptr(self.cand))
+        self.ticket = None
+        self.cu_reserved = None
         self._ws = None
+
+    def reserve_cus(self, n: int | None = None, ticket: bool | None = None):
+        """This batch's score passes stay off `n` compute units (default MOC_RESERVE_CUS) and hand their tiles out by
+        ticket: for a phase A that runs beside the meta-steps of another pass.  0 undoes it (static walk, whole chip);
+        ticket=True with n = 0: the ticketed walk alone (tests)."""
+        n = RESERVE_CUS if n is None else int(n)
+        use_ticket = (n > 0) if ticket is None else bool(ticket)
+        assert use_ticket or n <= 0, "reserved compute units need the ticketed walk"
+        if use_ticket and self.ticket is None:
+            self.ticket = torch.zeros(_lib.TICKET_WORDS, dtype=torch.int32, device=self.device)
+        self.c.tile_ticket = ptr(self.ticket) if use_ticket else None
+        self.cu_reserved = reserved_cus(self.device, n) if n > 0 else None
+        self.c.cu_reserved = ptr(self.cu_reserved)
 
     def set_mask(self, host_mask_u8: torch.Tensor, kept_rows: int):
         """New keep flags for the same visits (next epoch): async H2D into the resident mask array."""

@@ -150,6 +150,9 @@ class ResidentBags:
             # epoch e+1 (parameter-free) fills the other on a side stream (_resident_pass_setup)
             batches = [SlideBatch(self.X, sizes, C_, Ce, topj, topk, discard, mask=torch.ones(T, dtype=torch.uint8),
                                   x_starts=[self.starts[k] for k in order]) for _ in range(2)]
+            if PREFETCH_PHASE_A:
+                for b in batches:
+                    b.reserve_cus()         # phase A runs beside the meta-steps of the pass before: leave them CUs
             lab = torch.tensor([self.labels[k] for k in order], dtype=torch.int64).to(self.X.device)
             stage = [torch.empty(T, dtype=torch.uint8).pin_memory() for _ in range(2)]     # (only when torch itself must draw)
             drawer = engine.MaskDrawer(T, batches[0]._row_off_c, len(sizes))
@@ -158,7 +161,7 @@ class ResidentBags:
             # while a pass-ahead phase A is still in flight is not handed to someone else under it
             self.X.record_stream(side)
             for b in batches:
-                for t in (b.kept, b.n_kept, b.stats, b.sel_flag, b.sel_idx, b.sel_row, b.n_sel, b.cand, b.row_off, b.x_off):
+                for t in (b.kept, b.n_kept, b.stats, b.sel_flag, b.sel_idx, b.sel_row, b.n_sel, b.cand, b.row_off, b.x_off, b.ticket):
                     if t is not None:
                         t.record_stream(side)
             plan = self._plans[key] = {"batch": batches[0], "batches": batches, "labels": lab, "stage": stage,

@@ -873,3 +873,67 @@ def test_evaluation_reads_candidates_from_the_statistics_with_the_same_bits(dev,
         E.CAND_FROM_STATS = keep
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
     assert torch.isfinite(outs[0][0]).all()
+
+
+def test_cu_census_and_reserved_table(dev):
+    """moc_cu_census finds every compute unit of the device (MI355X: 8 XCDs x 32), and the reserved table is an equal
+    share of every XCD."""
+    E = _engine()
+    slots = E.cu_slots(dev)
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    assert len(slots) == n_cu, (len(slots), n_cu)
+    xccs = sorted({x for x, _ in slots})
+    assert len(xccs) == 8 and all(sum(1 for x, _ in slots if x == k) == n_cu // 8 for k in xccs)
+    for n in (8, 32, 64):
+        t = E.reserved_cus(dev, n).cpu()
+        bits = [(w, b) for w in range(128) for b in range(32) if (int(t[w]) >> b) & 1]
+        assert len(bits) == n
+        chosen = {((w * 32 + b) >> 8, (w * 32 + b) & 255) for w, b in bits}
+        assert chosen <= set(slots)
+        assert all(sum(1 for x, _ in chosen if x == k) == n // 8 for k in xccs)
+    assert E.reserved_cus(dev, 0) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,D,sizes", [(2, 512, [15000, 9000, 12001, 7]), (3, 512, [5000] * 6 + [33]), (30, 512, [6000, 4100, 300]),
+                                       (2, 256, [4000, 3000]), (40, 512, [3000, 2200])])
+def test_ticketed_score_pass_and_reserved_cus_give_the_same_bits(dev, dtype, C, D, sizes):
+    """The streaming score pass hands its tiles out by ticket (moc_batch_t.tile_ticket) and may stay off a set of compute
+    units (cu_reserved: its workgroups there end at once).  Which wave computes a tile changes nothing in the tile:
+    statistics and union flags are compared bit for bit with the static walk, masked and unmasked, twice in a row on
+    the same batch (the counter is cleared by every launch)."""
+    E = _engine()
+    if dtype != torch.float32 and C == 40:
+        pytest.skip("16-bit storage beyond three n-tiles takes the K-split kernels (no persistent workgroups)")
+    W, We = synth.make_bank(77 + C, D, C)
+    bags, _ = synth.make_slide_set(910 + C, sizes, D, We, C)
+    X = torch.cat(bags).to(dev).to(dtype).contiguous()
+    bank = E.Bank.get(W.to(dev), We.to(dev), dtype, dev)
+    g = torch.Generator().manual_seed(11)
+    mask = (torch.rand(sum(sizes), generator=g) > 0.5).to(torch.uint8)
+    for m in (None, mask):
+        outs = []
+        for ticket, reserve in ((False, 0), (True, 0), (True, 32), (True, 120)):
+            b = E.SlideBatch(X, sizes, C, C + 4, 100, 10, (), mask=m)
+            b.reserve_cus(reserve, ticket=ticket)
+            assert (b.c.cu_reserved is not None) == (reserve > 0) and (b.c.tile_ticket is not None) == ticket
+            for _ in range(2):
+                b.stats.fill_(float("nan"))
+                b.phase_a(bank)
+            torch.cuda.synchronize()
+            outs.append((b.stats.clone(), b.sel_flag.clone(), b.n_sel.clone(), b.sel_idx.clone(),
+                         b.n_kept.clone() if m is not None else None, int(b.c.flags)))
+        ref = outs[0]
+        off = [0]
+        for n in sizes:
+            off.append(off[-1] + n)
+        rows = (C + 5) if (ref[5] & 1) else (2 * C + 3)
+        for o in outs[1:]:
+            assert torch.equal(o[2], ref[2]), "n_sel differs"
+            for s_i in range(len(sizes)):
+                nk = int(ref[4][s_i]) if m is not None else sizes[s_i]
+                lo = off[s_i]
+                assert torch.equal(o[0][:rows, lo:lo + nk], ref[0][:rows, lo:lo + nk]), f"statistics of slide {s_i} differ"
+                assert torch.equal(o[1][lo:lo + nk], ref[1][lo:lo + nk]), f"union flags of slide {s_i} differ"
+                S = int(ref[2][s_i])
+                assert torch.equal(o[3][lo:lo + S], ref[3][lo:lo + S]), f"selected_index of slide {s_i} differs"

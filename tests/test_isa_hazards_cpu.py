@@ -28,10 +28,11 @@ def _check_kernel(name, lines, precise=True):
     retires everything issued textually before it (the row kernel's rotated loop)."""
     pend = {"vm": [], "lgkm": []}            # destination register sets, oldest first
     in_asm, n_loads, n_waits = False, {"vm": 0, "lgkm": 0}, {"vm": 0, "lgkm": 0}
+    alt_open = False
     for ln in lines:
         t = ln.strip()
         if t.startswith(";;#ASMSTART"):
-            in_asm = True
+            in_asm, alt_open = True, False
             continue
         if t.startswith(";;#ASMEND"):
             in_asm = False
@@ -47,12 +48,22 @@ def _check_kernel(name, lines, precise=True):
             assert not (addr & in_flight), f"{name}: `{t}` takes its address from in-flight registers"
             pend["vm"].append(set())
             continue
-        kind = "vm" if t.startswith("global_load_dwordx4") else "lgkm" if t.startswith("ds_read_b128") else None
+        # (global_atomic_add with return: the streaming kernels' tile tickets -- same in-order queue as the loads)
+        # global_load_dword: the dummy ticket operation of a unit that is not a tile boundary
+        kind = "vm" if (t.startswith("global_load_dword") or t.startswith("global_atomic_add")) else \
+            "lgkm" if t.startswith("ds_read_b128") else None
         if in_asm and kind:
             in_flight = set().union(*pend["vm"], *pend["lgkm"]) if (pend["vm"] or pend["lgkm"]) else set()
             addr = set().union(*[_regs(x) for x in toks[1:]]) if len(toks) > 1 else set()
             assert not (addr & in_flight), f"{name}: `{t}` takes its address from in-flight registers"
             assert not (_regs(toks[0]) & in_flight), f"{name}: `{t}` overwrites registers still in flight"
+            if t.startswith("global_load_dword ") and alt_open:
+                # the ticket operation: ONE asm statement holds the request and, behind a branch, the dummy load that runs
+                # instead of it -- one place in the queue, either destination may be the one in flight
+                pend[kind][-1] = pend[kind][-1] | _regs(toks[0])
+                alt_open = False
+                continue
+            alt_open = t.startswith("global_atomic_add")
             pend[kind].append(_regs(toks[0]))
             n_loads[kind] += 1
             continue
