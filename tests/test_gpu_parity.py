@@ -937,3 +937,36 @@ def test_ticketed_score_pass_and_reserved_cus_give_the_same_bits(dev, dtype, C, 
                 assert torch.equal(o[1][lo:lo + nk], ref[1][lo:lo + nk]), f"union flags of slide {s_i} differ"
                 S = int(ref[2][s_i])
                 assert torch.equal(o[3][lo:lo + S], ref[3][lo:lo + S]), f"selected_index of slide {s_i} differs"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ticketed_score_pass_with_every_compute_unit_reserved(dev, dtype):
+    """The table names EVERY compute unit: all workgroups but the first eight of the launch end at once, and those eight
+    (which never leave) draw from eight of the sixty-four counters -- the tiles of the other fifty-six reach them only
+    through the sweep behind the pipelined loop (one tile at a time from whichever counter still holds one).  Same bits
+    as the static walk, so no tile is lost or done with another tile's rows."""
+    E = _engine()
+    C, D, sizes = 2, 512, [9000, 41, 7000, 3, 5000]
+    W, We = synth.make_bank(123, D, C)
+    bags, _ = synth.make_slide_set(321, sizes, D, We, C)
+    X = torch.cat(bags).to(dev).to(dtype).contiguous()
+    bank = E.Bank.get(W.to(dev), We.to(dev), dtype, dev)
+    g = torch.Generator().manual_seed(3)
+    mask = (torch.rand(sum(sizes), generator=g) > 0.5).to(torch.uint8)
+    ref = E.SlideBatch(X, sizes, C, C + 4, 50, 10, (), mask=mask)
+    ref.phase_a(bank)
+    b = E.SlideBatch(X, sizes, C, C + 4, 50, 10, (), mask=mask)
+    b.reserve_cus(0, ticket=True)
+    everything = torch.full((128,), -1, dtype=torch.int32, device=dev)
+    b.cu_reserved = everything
+    b.c.cu_reserved = everything.data_ptr()
+    b.stats.fill_(float("nan"))
+    b.phase_a(bank)
+    torch.cuda.synchronize()
+    assert torch.equal(b.n_sel, ref.n_sel) and torch.equal(b.n_kept, ref.n_kept)
+    off = 0
+    for s_i, n in enumerate(sizes):
+        nk = int(ref.n_kept[s_i])
+        assert torch.equal(b.stats[:, off:off + nk], ref.stats[:, off:off + nk]), f"statistics of slide {s_i} differ"
+        assert torch.equal(b.sel_flag[off:off + nk], ref.sel_flag[off:off + nk])
+        off += n
