@@ -479,7 +479,7 @@ def main():
         if nt <= (3 if esz == 2 else 4):
             # (the look-ahead launches of a train pass take the ticketed form and stay off MOC_RESERVE_CUS compute units,
             # engine.RESERVE_CUS; four n-tiles keep the static walk)
-            ticketed = engine.RESERVE_CUS > 0 and M.PREFETCH_PHASE_A and nt < 4
+            ticketed = engine.RESERVE_CUS > 0 and M.PREFETCH_PHASE_A and nt == 1
             kname = (f"scores_stream_kernel<{16 if (D * esz) % 1024 == 0 else 8}, {half}, {nt}, {f16}, "
                      f"{'true' if ticketed else 'false'}>")
         elif esz == 2 and nt <= 8 and D % 64 == 0:

@@ -1631,12 +1631,12 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
 // its hidden row: dh[p][h] = mask_p[h] ? sum_i dz[p][i] W2[i][h] : 0 is re-formed on the fly.  The small
 // tensors are split by hidden unit: workgroup g also owns W2[:, 4g..4g+3] and b1[4g..4g+3] (16 wave-wide
 // reductions over the pairs), workgroup 0 b2.
-constexpr int WD_PCH = 128;      // pairs per chunk of the W1 gradient
+constexpr int WD_PCH_MIN = 128;  // pairs per chunk of the W1 gradient, at least (wide_pch: all pairs in one chunk when they fit)
 
 
 __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, float* pooled_out, int32_t* topk_idx_out,
                                                                  int32_t* topk_cnt_out, int PS_CAP, int region_bytes,
-                                                                 int external_pool) {
+                                                                 int external_pool, int WD_PCH) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FinishArgs& a = g.f;
     const int b = a.slide0, C = a.C, K = a.K, D = a.D;
@@ -1773,17 +1773,30 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
             // (requesting the next chunk's pieces a chunk ahead needs registers this 1024-thread kernel does not
             // have: at its 128-register cap hipcc waits for them at once and parks them in scratch -- measured
             // 3 % slower than loading each chunk where it is used)
-            for (int e = t; e < n * ppr; e += 1024) {
-                const int pp = e / ppr, v = e - pp * ppr;
-                *reinterpret_cast<uint4*>(xraw + (size_t)e * 16) =
-                    *reinterpret_cast<const uint4*>(a.X + (prow_s[c0 + pp] * D + d_lo) * esz + v * 16);
+            // (up to four pieces per thread requested before the first is stored: one round trip for a whole chunk of
+            // up to 4096 pieces -- ppr is 4, 8 or 16: shifts, no division)
+            const int ppr_sh = ppr == 4 ? 2 : ppr == 8 ? 3 : ppr == 16 ? 4 : ppr == 2 ? 1 : 0;
+            for (int e0 = 0; e0 < n * ppr; e0 += 4096) {
+                uint4 piece[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + t + u * 1024;
+                    const int ec = e < n * ppr ? e : n * ppr - 1;
+                    const int pp = ec >> ppr_sh, v = ec - (pp << ppr_sh);
+                    piece[u] = *reinterpret_cast<const uint4*>(a.X + (prow_s[c0 + pp] * D + d_lo) * esz + v * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + t + u * 1024;
+                    if (e < n * ppr) *reinterpret_cast<uint4*>(xraw + (size_t)e * 16) = piece[u];
+                }
             }
             if (c0 == 0) MOC_STAMP(50);
             {   // dh of the chunk: thread = (hidden unit t & 63, pair t >> 6 + 16 m); its four W2 entries stay in registers
                 const int h = t & 63;
                 const float w0 = W2s[h], w1 = W2s[H + h], w2 = W2s[2 * H + h], w3 = W2s[3 * H + h];
-#pragma unroll
-                for (int m = 0; m < WD_PCH / 16; ++m) {                // (unrolled: the eight rounds' LDS reads overlap)
+#pragma unroll 8
+                for (int m = 0; m < WD_PCH / 16; ++m) {                // (unrolled by eight: the rounds' LDS reads overlap)
                     const int pp = (t >> 6) + 16 * m;
                     if (pp < n4) {
                         float v = 0.f;
@@ -2236,19 +2249,27 @@ int wide_cap(const moc_batch_t* B) {
     while (cap > 64 && (size_t)B->C * cap * 8 > 64 * 1024) cap >>= 1;
     return cap;
 }
-size_t wide_region(const moc_batch_t* B) {
+size_t wide_region(const moc_batch_t* B, int pch) {
     const size_t lists = (size_t)B->C * wide_cap(B) * 8;
-    const size_t rows = (size_t)WD_PCH * ((B->D / 16) * moc_elem_size(B->dtype) + 64 * sizeof(float));   // row pieces + dh of one chunk
+    const size_t rows = (size_t)pch * ((B->D / 16) * moc_elem_size(B->dtype) + 64 * sizeof(float));   // row pieces + dh of one chunk
     return ((lists > rows ? lists : rows) + 15) & ~(size_t)15;
 }
-size_t wide_smem(const moc_batch_t* B) {
+size_t wide_smem(const moc_batch_t* B, int pch) {
     const size_t C = B->C, PK = C * B->topk;
-    return wide_region(B) + C * 16 * 8 + C * 4 * 3 + PK * 4 + PK * 16 * 2 + PK * 8 + PK * 4 + (4 * H + 32) * 4 + 8 + PK * 8;
+    return wide_region(B, pch) + C * 16 * 8 + C * 4 * 3 + PK * 4 + PK * 16 * 2 + PK * 8 + PK * 4 + (4 * H + 32) * 4 + 8 + PK * 8;
+}
+// pairs per chunk of the W1 gradient: all C * K of them in ONE chunk when its row pieces + dh fit beside the rest
+// (EBRAINS-30: 300 pairs, 97 KiB at bf16) -- one gather round trip and one barrier pair instead of three; else the
+// largest multiple of 32 that fits, at least WD_PCH_MIN
+int wide_pch(const moc_batch_t* B) {
+    int pch = (B->C * B->topk + 31) & ~31;
+    while (pch > WD_PCH_MIN && wide_smem(B, pch) > (size_t)FS_MAX_DYN_LDS) pch -= 32;
+    return pch < WD_PCH_MIN ? WD_PCH_MIN : pch;
 }
 bool fused_wide_ok(const moc_batch_t* B, const moc_meta_ws_t* ws) {
     if (!ws->W2_alt || B->topk > 16 || B->C > 64) return false;      // (S > 8192: pooling by topk_mean_kernel first)
     if (B->D % 512 != 0 || B->D > 1024) return false;        // D/16 = 32 or 64 columns per workgroup
-    return wide_smem(B) <= (size_t)FS_MAX_DYN_LDS;
+    return wide_smem(B, WD_PCH_MIN) <= (size_t)FS_MAX_DYN_LDS;
 }
 // 0: three launches, 1: pool_w1_step_kernel, 2: pool_w1_step_wide_kernel
 int fused_step_mode(const moc_batch_t* B, const moc_meta_ws_t* ws) {
@@ -2305,8 +2326,9 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
             if (int rc = launch_pool(B, ws, slide, 1, s)) return rc;
             a.topk_idx = ws->topk_idx; a.topk_cnt = ws->topk_cnt;
         }
-        pool_w1_step_wide_kernel<<<H / 4, 1024, wide_smem(B), s>>>(g, ws->pooled, ws->topk_idx, ws->topk_cnt, wide_cap(B),
-                                                                    (int)wide_region(B), external);
+        const int pch = wide_pch(B);
+        pool_w1_step_wide_kernel<<<H / 4, 1024, wide_smem(B, pch), s>>>(g, ws->pooled, ws->topk_idx, ws->topk_cnt, wide_cap(B),
+                                                                         (int)wide_region(B, pch), external, pch);
         MOC_CHECK_LAUNCH("moc_fused_step(wide)");
         return MOC_OK;
     }

@@ -696,7 +696,8 @@ def _seq_plan(sh: SeqShardedBags, m: int, bank, args):
         ts = [st["send_feat"], st["send_cand"], st["send_nsel"], st["all_nsel"], st["recv_cand"], cb.X, cb.cand, cb.n_sel, cb.row_off]
         if st["local"] is not None:
             b = st["local"]
-            b.reserve_cus()                      # its phase A runs beside the meta-steps of the pass before
+            if bank.Ce <= 16:
+                b.reserve_cus()                  # its phase A runs beside the meta-steps of the pass before (main_moc.train_plan)
             ts += [t for t in (b.kept, b.n_kept, b.stats, b.sel_flag, b.sel_idx, b.sel_row, b.n_sel, b.cand, b.row_off, b.x_off, b.ticket) if t is not None]
             X.record_stream(side)
         for t in ts:

@@ -150,9 +150,12 @@ class ResidentBags:
             # epoch e+1 (parameter-free) fills the other on a side stream (_resident_pass_setup)
             batches = [SlideBatch(self.X, sizes, C_, Ce, topj, topk, discard, mask=torch.ones(T, dtype=torch.uint8),
                                   x_starts=[self.starts[k] for k in order]) for _ in range(2)]
-            if PREFETCH_PHASE_A:
+            if PREFETCH_PHASE_A and Ce <= 16:
+                # phase A runs beside the meta-steps of the pass before: leave them CUs.  (Banks of one n-tile only: wider
+                # ones run ONE score workgroup per CU -- thirty classes with 64 CUs left free: score pass 242 -> 447 us,
+                # 18.9 -> 18.8 k meta-steps/s.)
                 for b in batches:
-                    b.reserve_cus()         # phase A runs beside the meta-steps of the pass before: leave them CUs
+                    b.reserve_cus()
             lab = torch.tensor([self.labels[k] for k in order], dtype=torch.int64).to(self.X.device)
             stage = [torch.empty(T, dtype=torch.uint8).pin_memory() for _ in range(2)]     # (only when torch itself must draw)
             drawer = engine.MaskDrawer(T, batches[0]._row_off_c, len(sizes))
