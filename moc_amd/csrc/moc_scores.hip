@@ -692,11 +692,13 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
     // Instead: issue the NF loads of the next unit, then wait until only those NF are outstanding
     // -- everything older (the current unit's loads, the previous epilogue's stores) has landed.
     // Tiles by ticket (DYN) or by a static stride per wave.  Tickets: MOC_TICKET_QUEUES counters, 256 bytes apart; counter
-    // q hands out the tiles t * Q + q (t = 0, 1, ...).  A wave draws from the counter of its own XCD in the pipelined
-    // loop; when that has run out it leaves the loop and takes what any OTHER counter still holds, one tile at a time
+    // q hands out the tiles t * Q + q (t = 0, 1, ...), two per ticket.  A wave draws from ONE counter in the pipelined loop
+    // (one of its XCD's eight: s_counter above); when that has run out it leaves the loop and takes what any OTHER
+    // counter still holds, one tile at a time
     // (the sweep behind the loop: slow, and idle unless an XCD has no workgroup of this launch left) -- so every tile is
     // handed out whatever workgroups exist and wherever they sit.  (ONE counter serialised the whole launch: a returning
-    // atomic on one address takes ~16 ns on this part, 15,000 tiles x 16 ns = 2.3x the kernel's own time.)  A wave's
+    // atomic on one address takes ~16 ns on this part, 15,000 tiles x 16 ns = 2.3x the kernel's own time; eight counters
+    // 1.26x, thirty-two or sixty-four 1.07x.)  A wave's
     // state: `g` the tile whose loads are being issued, `g_next` the one after it (known), and tickets in flight.  A
     // request is an atomic with return issued by hand (lane 0 only, exec switched inside the asm) so that the compiler's
     // wait insertion does not see it.
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void scores_stream_kernel(Sco
     static_assert(NQ % 8 == 0 && NQ <= 64, "one ballot over the counters");
     constexpr int DONE = 0x7fffffff;
     int g, g_next = 0, ch = 0;
-    int q = 0;                                                    // this wave's counter: its XCD's
+    int q = 0;                                                    // this wave's counter
     // vmcnt retires IN ORDER, so where the request sits among the loads decides who waits for it.  Every unit issues
     // exactly one ticket operation right BEFORE its NF loads -- the request itself at a tile boundary, a dummy 4-byte load
     // otherwise -- so that every counted wait is vmcnt(NF + 1): it retires the previous unit's loads and the ticket
