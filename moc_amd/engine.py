@@ -103,6 +103,25 @@ def reserved_cus(device, n):
     return _reserved[key]
 
 
+_stream_objs = {}
+
+
+def stream_obj():
+    """torch's Stream object of the current stream, cached by raw handle: Event.record() / Event.wait() without a stream
+    argument go through torch.cuda.current_stream(), 7-9 us a call (device-index look-ups, an availability check that reads the
+    environment) -- three of them per pass, one in front of the pass's first launch."""
+    if _raw_stream is None:
+        return torch.cuda.current_stream()
+    dev = torch.cuda.current_device()
+    key = (dev, _raw_stream(dev))
+    obj = _stream_objs.get(key)
+    if obj is None:
+        if len(_stream_objs) > 64:
+            _stream_objs.clear()
+        obj = _stream_objs[key] = torch.cuda.current_stream()
+    return obj
+
+
 def timed_scores(batch, bank):
     """moc_scores_timed on the current stream: -> (start, stop) torch events holding the score kernel's own time stamps
     (start.elapsed_time(stop) after a synchronisation = the kernel's duration as rocprofv3 reports it)."""

@@ -304,7 +304,7 @@ def _issue_phase_a(plan, turn, bank, rng_before, host_wait=None, chain_plan=None
     batch.use_host_mask(stage, kept, max_kept)          # read in place by the compaction kernel: no upload
     batch.phase_a(plan["bank"])
     ev = torch.cuda.Event()
-    ev.record()
+    ev.record(engine.stream_obj())
     if buf is not None:
         plan["drawer"].attach(buf, ev)                  # ... so the buffer is free again when phase A has run
     else:
@@ -331,7 +331,7 @@ def _resident_pass_setup(res, device, args):
     ahead, plan["ahead"] = plan["ahead"], None
     if ahead is not None and ahead["bank"] is bank and ahead["after"] is not None and torch.equal(ahead["before"], now):
         torch.set_rng_state(ahead["after"])             # the draws happened: put the generator where they leave it
-        ahead["done"].wait()                            # (the current stream waits; no Stream object is built)
+        ahead["done"].wait(engine.stream_obj())         # (the current stream waits; its Stream object is a cached one)
         plan["turn"] = ahead["turn"]
     else:
         if ahead is not None:
@@ -377,7 +377,7 @@ def resident_pass_done(res, device, args):
     # the other set was last read by the PREVIOUS pass's meta-steps (their mark was left one call ago), so the
     # side stream waits for that one only and phase A of the next pass overlaps THIS pass's meta-steps
     mark = torch.cuda.Event()
-    mark.record()                                       # (on the current stream -- `main` below)
+    mark.record(engine.stream_obj())                    # (on the current stream -- `main` below)
     plan.setdefault("steps_done", [None, None])[plan["turn"]] = mark
     nplan = _next_plan(res, plan, bank, args)
     if nplan is None:
