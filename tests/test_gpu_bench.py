@@ -33,7 +33,10 @@ def test_one_gpu_line(gpu_device):
     assert ss["epochs"] == 10 and ss["steps"] == 320 and ss["value"] > d["value"] * 0.8
     roof = d["roofline"]
     assert d["config"]["bag_storage"] == "fp32"                      # the storage pinned to the reference's main(); bf16 is an extra block
-    assert roof["bound"] == "hbm" and roof["kernel"] == "scores_stream_kernel<16, false, 1, false>" and roof["peak"] == 8000.0
+    # (the timed launches are look-ahead launches: the ticketed form, off the compute units left to the meta-steps)
+    assert roof["bound"] == "hbm" and roof["kernel"] == "scores_stream_kernel<16, false, 1, false, true>" and roof["peak"] == 8000.0
+    assert roof["placement"]["compute_units_left_to_the_meta_steps"] == 64
+    assert roof["whole_chip"]["kernel"] == "scores_stream_kernel<16, false, 1, false, false>" and roof["whole_chip"]["frac"] > roof["frac"] * 0.9
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.2 < roof["frac"] < 1.0
     assert roof["traffic"] is None or "traffic_source" in roof       # a 20-slide launch matches no committed capture
     cpu = d["cpu_baseline"]
