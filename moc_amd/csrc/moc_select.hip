@@ -343,6 +343,7 @@ __global__ __launch_bounds__(1024, MINW) void select_group_kernel(SelectArgs a, 
         for (int i = threadIdx.x; i < nk; i += 1024) flag[i] = 1;
         return;
     }
+    MOC_STAMP(20);
     auto load_row = [&](int i, float (&r)[SG_COLS]) {      // the group's sources at slot i: independent loads
 #pragma unroll
         for (int t = 0; t < SG_COLS; ++t) r[t] = src[t] >= 0 ? srow[(int64_t)src[t] * a.stride + i] : 0.f;
@@ -379,7 +380,9 @@ __global__ __launch_bounds__(1024, MINW) void select_group_kernel(SelectArgs a, 
             for (int q = 0; q < SG_COLS; ++q) pool[q * 1024 + threadIdx.x] = ((unsigned long long)k[q] << 32) | ((unsigned long long)q << 29);
         }
         __syncthreads();
+        MOC_STAMP(21);
         pool_radix_select(pool, SG_COLS * 1024, active, ks, hist, st);
+        MOC_STAMP(22);
         uint32_t T0[SG_COLS];
 #pragma unroll
         for (int q = 0; q < SG_COLS; ++q) T0[q] = (uint32_t)st[q * 8];
@@ -429,9 +432,11 @@ __global__ __launch_bounds__(1024, MINW) void select_group_kernel(SelectArgs a, 
             }
         }
         __syncthreads();
+        MOC_STAMP(23);
         const int np = n_pool[0];
         if (np <= SG_POOL) {                               // (uniform)
             pool_radix_select(pool, np, active, a.topj, hist, st);
+            MOC_STAMP(24);
             // a column is settled when it had at least topj candidates and no tie straddles the boundary
             for (int i = threadIdx.x; i < np; i += 1024) {
                 const unsigned long long e = pool[i];
@@ -439,6 +444,7 @@ __global__ __launch_bounds__(1024, MINW) void select_group_kernel(SelectArgs a, 
                 const int* sq = st + q * 8;
                 if (sq[4] && sq[1] == sq[2] && (uint32_t)(e >> 32) >= (uint32_t)sq[0]) flag[(uint32_t)e & 0x1FFFFFFFu] = 1;
             }
+            MOC_STAMP(25);
 #pragma unroll
             for (int q = 0; q < SG_COLS; ++q)
                 if ((active >> q & 1u) && !(st[q * 8 + 4] && st[q * 8 + 1] == st[q * 8 + 2])) todo |= 1u << q;

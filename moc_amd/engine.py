@@ -77,30 +77,44 @@ def reserved_cus(device, n):
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (idx, n)
     if key not in _reserved:
-        slots = cu_slots(dev)
-        assert n <= len(slots) // 2, f"MOC_RESERVE_CUS={n}: the device has {len(slots)} compute units"
-        xccs = sorted({x for x, _ in slots})
-        chosen = []
-        per = [n // len(xccs) + (1 if i < n % len(xccs) else 0) for i in range(len(xccs))]
-        for x, want in zip(xccs, per):
-            groups = {}
-            for _, s_ in (t for t in slots if t[0] == x):
-                groups.setdefault(s_ >> 4, []).append(s_)                # HW_ID[15:12] = SE | SH; [11:8] = CU
-            order = [sorted(g, reverse=True) for _, g in sorted(groups.items())]
-            k = 0
-            while want > 0:
-                g = order[k % len(order)]
-                if g:
-                    chosen.append((x, g.pop(0)))
-                    want -= 1
-                k += 1
-        words = [0] * 128
-        for x, s_ in chosen:
-            bit = x * 256 + s_
-            words[bit >> 5] |= 1 << (bit & 31)
+        words = reserved_words(choose_reserved_slots(cu_slots(dev), n))
         t = torch.tensor([w - (1 << 32) if w >= (1 << 31) else w for w in words], dtype=torch.int32)
         _reserved[key] = t.to(dev)
     return _reserved[key]
+
+
+def choose_reserved_slots(slots, n):
+    """`n` of the (xcc, HW_ID[15:8]) slots: an equal share of every XCD (the first n % XCDs get one more), inside an XCD
+    dealt round-robin over its shader engines / arrays (HW_ID[15:12]), the highest CU id of each first.  Pure."""
+    n = int(n)
+    assert 0 < n <= len(slots) // 2, f"{n} reserved compute units of {len(slots)}"
+    xccs = sorted({x for x, _ in slots})
+    chosen = []
+    per = [n // len(xccs) + (1 if i < n % len(xccs) else 0) for i in range(len(xccs))]
+    for x, want in zip(xccs, per):
+        groups = {}
+        for _, s_ in (t for t in slots if t[0] == x):
+            groups.setdefault(s_ >> 4, []).append(s_)                # HW_ID[15:12] = SE | SH; [11:8] = CU
+        order = [sorted(g, reverse=True) for _, g in sorted(groups.items())]
+        assert want <= sum(len(g) for g in order), f"XCD {x} has fewer than {want} compute units"
+        k = 0
+        while want > 0:
+            g = order[k % len(order)]
+            if g:
+                chosen.append((x, g.pop(0)))
+                want -= 1
+            k += 1
+    return chosen
+
+
+def reserved_words(chosen):
+    """The 128-word bitmap moc_batch_t.cu_reserved points at: bit xcc * 256 + HW_ID[15:8]."""
+    words = [0] * 128
+    for x, s_ in chosen:
+        assert 0 <= x < 16 and 0 <= s_ < 256
+        bit = x * 256 + s_
+        words[bit >> 5] |= 1 << (bit & 31)
+    return words
 
 
 _stream_objs = {}

@@ -1,0 +1,44 @@
+"""Host side of the score pass's placement (include/moc_hip.h: compute units kept free of the score pass): which slots
+the reserved table names, given what moc_cu_census found.  No GPU: the census result is made up here."""
+import pytest
+
+from moc_amd import engine as E
+
+
+def _mi355x_like(harvest=()):
+    """8 XCDs x 4 shader engines x 8 CUs, HW_ID[15:8] = SE << 5 | SH << 4 | CU; `harvest`: slots that do not exist."""
+    slots = [(x, (se << 5) | cu) for x in range(8) for se in range(4) for cu in range(9)]
+    gone = set(harvest) | {(x, (se << 5) | 8) for x in range(8) for se in range(4)}     # nine physical, eight active
+    return sorted(t for t in slots if t not in gone)
+
+
+@pytest.mark.parametrize("n", [8, 32, 64, 72, 100])
+def test_an_equal_share_of_every_xcd_spread_over_its_shader_engines(n):
+    slots = _mi355x_like()
+    assert len(slots) == 256
+    chosen = E.choose_reserved_slots(slots, n)
+    assert len(chosen) == n == len(set(chosen)) and set(chosen) <= set(slots)
+    per_xcd = [sum(1 for x, _ in chosen if x == k) for k in range(8)]
+    assert max(per_xcd) - min(per_xcd) <= 1 and sum(per_xcd) == n
+    for k in range(8):
+        per_se = [sum(1 for x, s in chosen if x == k and s >> 5 == se) for se in range(4)]
+        assert max(per_se) - min(per_se) <= 1, (k, per_se)
+    # the highest CU ids of an engine go first
+    for x, s in chosen:
+        higher = [t for t in slots if t[0] == x and t[1] >> 4 == s >> 4 and t[1] > s]
+        assert all(t in chosen for t in higher)
+
+
+def test_irregular_harvest_and_bitmap():
+    slots = _mi355x_like(harvest={(0, (1 << 5) | 7), (0, (1 << 5) | 6), (5, (3 << 5) | 0)})
+    chosen = E.choose_reserved_slots(slots, 64)
+    assert len(set(chosen)) == 64 and set(chosen) <= set(slots)
+    words = E.reserved_words(chosen)
+    assert len(words) == 128 and sum(bin(w).count("1") for w in words) == 64
+    for x, s in chosen:
+        bit = x * 256 + s
+        assert words[bit >> 5] >> (bit & 31) & 1
+    with pytest.raises(AssertionError):
+        E.choose_reserved_slots(slots, len(slots))          # more than half of the chip: refused
+    with pytest.raises(AssertionError):
+        E.choose_reserved_slots(slots, 0)
