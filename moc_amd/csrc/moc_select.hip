@@ -371,7 +371,12 @@ __global__ __launch_bounds__(1024, MINW) void select_group_kernel(SelectArgs a, 
         int ks = (int)((2048ll * a.topj + nk - 1) / nk) + 4;
         ks = ks > 1024 ? 1024 : ks;
         {
-            const int i = (int)(((int64_t)threadIdx.x * nk) >> 10);
+            // 64 evenly spaced runs of 16 consecutive slots (64 bytes of a column each), not 1024 single slots: single
+            // slots 15 apart touch EVERY 128-byte line of the eight columns -- the sample then moves as many bytes as the
+            // sweep itself (the kernel is HBM-bound: stamps: sample 11.8 + sweep 36 us of a workgroup's 75).  A run of 16
+            // neighbours says less than 16 scattered slots where neighbouring patches look alike; the bound only sizes
+            // the candidate lists (checked below), it does not decide anything
+            const int i = (int)(((int64_t)(threadIdx.x >> 4) * nk) >> 6) + (int)(threadIdx.x & 15);
             float r[SG_COLS];
             uint32_t k[SG_COLS];
             load_row(i, r);
