@@ -856,6 +856,170 @@ __global__ __launch_bounds__(1024) void topk_mean_kernel(TopkArgs a) {
     if (threadIdx.x == 0 && a.cnt_out) a.cnt_out[out] = k;
 }
 
+
+// ---- top-K mean, ONE WAVE per (segment, class): for launches of thousands of tasks (an evaluation pass of a wide bank:
+// 202 slides x 30 classes) -- the 1,024-thread kernel above runs them twelve rounds of 512 workgroups with six barriers
+// each (240 us per 202 x 15,000 x 30); here every task is in flight at once and no wave waits for another.
+// K <= 16.  A lower bound T0 of the k-th largest key from the lane maxima of a sample (long segments) or of all keys; one
+// sweep: keys >= T0 into the wave's LDS list (WT_CAP entries, positions by ballot prefix); then k rounds of wave maximum
+// over (key << 32 | ~row): the order of the kernel above -- key descending, ties by ascending row -- and the same
+// sequential sum.  A list that overflows even with the bound from all keys (flat key distributions): k rounds over ALL
+// keys, each finding the largest entry below the previous one (slow, exact, rare).
+constexpr int WT_CAP = 256;          // candidate entries per wave
+constexpr int WT_WAVES = 4;          // tasks per workgroup
+
+__global__ __launch_bounds__(64 * WT_WAVES) void topk_mean_wave_kernel(TopkArgs a, int n_tasks) {
+    __shared__ unsigned long long cand_s[WT_WAVES][WT_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int task = blockIdx.x * WT_WAVES + wave;
+    if (task >= n_tasks) return;                                   // (no barrier below: waves are on their own)
+    const int seg = a.seg0 + task / a.C, c = task - (task / a.C) * a.C;
+    const int64_t base = a.seg_off[seg];
+    const int n = a.seg_len ? a.seg_len[seg] : (int)(a.seg_off[seg + 1] - base);
+    const int out = seg * a.C + c;
+    if (n <= 0) {   // mean over an empty set: NaN, like torch
+        if (lane == 0) {
+            a.pooled[out] = __uint_as_float(0x7FC00000u);
+            if (a.cnt_out) a.cnt_out[out] = 0;
+        }
+        return;
+    }
+    const float* kcol = a.keys + (int64_t)c * a.key_stride + base;
+    const float* vcol = a.vals + (int64_t)c * a.val_stride + base;
+    const uint32_t flip = a.smallest ? 0xFFFFFFFFu : 0u;
+    auto keyfn = [&](int i) { return moc_key_desc(kcol[i]) ^ flip; };
+    const int k = a.K < n ? a.K : n;
+    unsigned long long* cand = cand_s[wave];
+    unsigned long long mine[WT_CAP / 64];
+#pragma unroll
+    for (int q = 0; q < WT_CAP / 64; ++q) mine[q] = 0ull;
+    bool listed = false;                                           // wave-uniform: `mine` holds every candidate
+    if (n <= WT_CAP) {
+        // short segments: every key is a candidate
+#pragma unroll
+        for (int q = 0; q < WT_CAP / 64; ++q) {
+            const int i = q * 64 + lane;
+            if (i < n) mine[q] = ((unsigned long long)keyfn(i) << 32) | (uint32_t)(~(uint32_t)i);
+        }
+        listed = true;
+    } else {
+        // ---- the bound: the k-th largest of the 64 lane maxima over (a) eight runs of 256 consecutive keys spread over the
+        // segment -- long segments: one pass over the keys instead of two, the kernel is bound by those bytes -- or (b) all
+        // keys.  Either is a lower bound of the k-th largest key (k lanes hold a key >= it; every lane holds a key: n > 256).
+        auto lane_bound = [&](bool sample) -> uint32_t {
+            uint32_t mx = 0;
+            if (sample) {
+                for (int r = 0; r < 8; ++r) {
+                    const int start = (int)(((int64_t)r * n) >> 3);
+                    uint32_t u[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = start + q * 64 + lane;
+                        u[q] = i < n ? keyfn(i) : 0u;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mx = u[q] > mx ? u[q] : mx;
+                }
+            } else {
+                for (int i0 = 0; i0 < n; i0 += 512) {
+                    uint32_t u[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int i = i0 + q * 64 + lane;
+                        u[q] = i < n ? keyfn(i) : 0u;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) mx = u[q] > mx ? u[q] : mx;
+                }
+            }
+            uint32_t T = 0;
+            bool alive = true;
+            for (int r = 0; r < k; ++r) {                           // k rounds, one lane knocked out per round
+                const uint32_t best = (uint32_t)wave_max_u64(alive ? (unsigned long long)mx : 0ull);
+                const unsigned long long m = __ballot(alive && mx == best);
+                const int first = __ffsll((long long)m) - 1;
+                if (lane == first) alive = false;
+                T = best;
+            }
+            return T;
+        };
+        // ---- the sweep: candidates >= T0, positions by ballot prefix
+        auto collect = [&](uint32_t T0) -> int {
+            int cnt = 0;
+            for (int i0 = 0; i0 < n; i0 += 512) {
+                uint32_t u[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = i0 + q * 64 + lane;
+                    u[q] = i < n ? keyfn(i) : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = i0 + q * 64 + lane;
+                    const bool hit = i < n && u[q] >= T0;
+                    const unsigned long long m = __ballot(hit);
+                    if (m == 0ull) continue;                        // (uniform)
+                    const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                    if (hit && pos < WT_CAP) cand[pos] = ((unsigned long long)u[q] << 32) | (uint32_t)(~(uint32_t)i);
+                    cnt += __popcll(m);
+                }
+            }
+            return cnt;
+        };
+        const bool sampled = n > 4096;
+        int cnt = collect(lane_bound(sampled));
+        if (cnt > WT_CAP && sampled) cnt = collect(lane_bound(false));   // (the runs were not typical of the segment: the bound from all keys)
+        if (cnt <= WT_CAP) {
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS writes, before it reads them back
+#pragma unroll
+            for (int q = 0; q < WT_CAP / 64; ++q) mine[q] = q * 64 + lane < cnt ? cand[q * 64 + lane] : 0ull;
+            listed = true;
+        }
+    }
+    // ---- the k largest in order; lane r keeps entry r
+    unsigned long long mylist = 0ull;
+    if (listed) {
+        for (int r = 0; r < k; ++r) {
+            unsigned long long best = 0ull;
+#pragma unroll
+            for (int q = 0; q < WT_CAP / 64; ++q) best = mine[q] > best ? mine[q] : best;
+            best = wave_max_u64(best);                              // entries are distinct (row in the low word)
+#pragma unroll
+            for (int q = 0; q < WT_CAP / 64; ++q) mine[q] = mine[q] == best ? 0ull : mine[q];
+            if (lane == r) mylist = best;
+        }
+    } else {
+        unsigned long long prev = 0ull;
+        for (int r = 0; r < k; ++r) {
+            unsigned long long best = 0ull;
+            for (int i = lane; i < n; i += 64) {
+                const unsigned long long e = ((unsigned long long)keyfn(i) << 32) | (uint32_t)(~(uint32_t)i);
+                best = ((r == 0 || e < prev) && e > best) ? e : best;
+            }
+            best = wave_max_u64(best);
+            if (lane == r) mylist = best;
+            prev = best;
+        }
+    }
+    if (a.idx_out && lane < a.K)
+        a.idx_out[(int64_t)out * a.K + lane] = lane < k ? (int32_t)(~(uint32_t)(mylist & 0xFFFFFFFFull)) : -1;
+    // mean of the k values, summed in rank order (as the kernel above does for k <= 64)
+    const bool same = a.keys == a.vals && a.key_stride == a.val_stride;
+    float v = 0.f;
+    if (lane < k) {
+        const uint32_t u = (uint32_t)(mylist >> 32) ^ flip;
+        if (same && u != 0x80000000u) v = __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+        else v = vcol[(int)(~(uint32_t)(mylist & 0xFFFFFFFFull))];
+    }
+    float sum = 0.f;
+    for (int r = 0; r < k; ++r) sum += __shfl(v, r, 64);
+    if (lane == 0) {
+        a.pooled[out] = sum / (float)k;
+        if (a.cnt_out) a.cnt_out[out] = k;
+    }
+}
+
 }  // namespace
 
 extern "C" int moc_select(const moc_batch_t* B, moc_stream_t stream) {
@@ -969,6 +1133,14 @@ int moc_launch_topk_mean(const float* keys, int64_t key_stride, const float* val
     a.C = C; a.K = K; a.smallest = smallest; a.seg0 = seg0;
     int P = 1;
     while (P < K) P <<= 1;
+    // thousands of small tasks (an evaluation pass of a wide bank): one wave each, all in flight at once
+    static const int wave_min = getenv("MOC_TOPK_WAVE_MIN") ? atoi(getenv("MOC_TOPK_WAVE_MIN")) : 2048;     // (diagnostic knob)
+    if (K <= 16 && (int64_t)C * n_seg >= wave_min) {
+        const int n_tasks = C * n_seg;
+        topk_mean_wave_kernel<<<moc_cdiv(n_tasks, WT_WAVES), 64 * WT_WAVES, 0, s>>>(a, n_tasks);
+        MOC_CHECK_LAUNCH("moc_topk_mean(wave)");
+        return MOC_OK;
+    }
     // 1024 threads: the select passes are chains of dependent key reads, one per blockDim.x keys
     topk_mean_kernel<<<dim3(C, n_seg), 1024, (size_t)P * 12 + 288 * sizeof(int) + (K <= 16 ? 96 + TK_CAND * 8 : 0), s>>>(a);
     MOC_CHECK_LAUNCH("moc_topk_mean");

@@ -970,3 +970,49 @@ def test_ticketed_score_pass_with_every_compute_unit_reserved(dev, dtype):
         assert torch.equal(b.stats[:, off:off + nk], ref.stats[:, off:off + nk]), f"statistics of slide {s_i} differ"
         assert torch.equal(b.sel_flag[off:off + nk], ref.sel_flag[off:off + nk])
         off += n
+
+
+@pytest.mark.parametrize("K,smallest,same", [(10, False, True), (16, False, False), (1, True, False), (10, True, True), (3, False, True)])
+def test_wave_per_task_topk_gives_the_workgroup_kernels_bits(dev, K, smallest, same):
+    """Launches of thousands of (segment, class) tasks take one WAVE per task (topk_mean_wave_kernel); fewer take the
+    1,024-thread kernel.  Same pooled values, same chosen rows in the same order (key, then lower row first), same
+    counts: ragged segments (1 ... 15,000 rows, shorter than K, exactly 64 / 256 / 257), ties everywhere (quantised keys),
+    flat segments (every key equal: the candidate list overflows and the exact slow path runs), keys != values."""
+    E = _engine()
+    g = torch.Generator().manual_seed(100 + K)
+    lens = [1, 2, 5, 15, 16, 17, 63, 64, 65, 255, 256, 257, 300, 1000, 4097, 15000, 7, 9000] + [int(v) for v in torch.randint(1, 3000, (110,), generator=g)]
+    Cc = 20                                                        # 128 segments x 20 classes = 2,560 tasks: the wave kernel
+    off = [0]
+    for n in lens:
+        off.append(off[-1] + n)
+    N = off[-1]
+    keys = torch.randn(Cc, N, generator=g)
+    keys[3] = torch.round(keys[3] * 4) / 4                         # heavy ties
+    keys[4] = 0.25                                                 # flat: every key equal
+    keys[5, : off[16]] = -1.5                                      # flat prefix incl. the 15,000-row segment
+    keys[6] = torch.round(keys[6])                                 # a few distinct values only
+    keys[7, off[15] + 400: off[15] + 1800] += 20.0                 # the 15,000-row segment's top keys lie between the sampled runs
+    keys[8, off[15]: off[16]] = torch.sort(keys[8, off[15]: off[16]])[0]      # ascending
+    keys[9, off[15]: off[16]] = torch.sort(keys[9, off[15]: off[16]], descending=True)[0]
+    vals = keys if same else torch.randn(Cc, N, generator=g)
+    keys_d, vals_d = keys.to(dev), (keys.to(dev) if same else vals.to(dev))
+    if same:
+        vals_d = keys_d
+    seg = torch.tensor(off, dtype=torch.int64, device=dev)
+    p_w, i_w, c_w = E.topk_mean(keys_d, vals_d, K, smallest=smallest, want_idx=True, seg_off=seg)
+    torch.cuda.synchronize()
+    # the same segments in launches of 64 (1,280 tasks: the workgroup kernel)
+    p_r, i_r, c_r = [], [], []
+    for s0 in range(0, len(lens), 64):
+        sub = seg[s0:s0 + 65]
+        p, i, c = E.topk_mean(keys_d, vals_d, K, smallest=smallest, want_idx=True, seg_off=sub)
+        p_r.append(p); i_r.append(i); c_r.append(c)
+    p_r, i_r, c_r = torch.cat(p_r), torch.cat(i_r), torch.cat(c_r)
+    assert torch.equal(c_w, c_r)
+    assert torch.equal(i_w, i_r), "chosen rows / their order differ"
+    assert torch.equal(p_w.view(torch.int32), p_r.view(torch.int32)), "pooled values differ in bits"
+    # and against plain torch on one ragged segment
+    s_i, c_i = 15, 0
+    col = keys[c_i, off[s_i]:off[s_i + 1]]
+    order = torch.argsort(-col if not smallest else col, stable=True)[:K]
+    assert i_w[s_i, c_i].cpu().tolist() == order.tolist()
