@@ -593,10 +593,17 @@ __global__ __launch_bounds__(256) void meta_forward64_kernel(FwdArgs a) {
 //     use them (an ordinary LDS read would make hipcc wait vmcnt(0) first: the DMA in flight writes LDS too);
 //   * the mix's operands (the row's candidate scores, the first 16 classes) are requested at kernel start, consumed last.
 // Same products in the same order per (row, hidden unit) as the 16- and 64-row kernels: bit-identical outputs.
-constexpr int F128_ROWS = 128, F128_KC = 4;
-constexpr int F128_BUF = (F128_ROWS / 16) * F128_KC * 1024;                  // 32 KiB: one chunk of the workgroup's rows
-constexpr int F128_XB = 2 * F128_BUF > F128_ROWS * (H + 1) * 4 ? 2 * F128_BUF : F128_ROWS * (H + 1) * 4;
-constexpr int F128_LDS = F128_XB + F128_ROWS * 4 * 4 + 4 * H * 4;            // + gates + W2: 68.6 KiB, two workgroups per CU
+// k-steps (64 bytes of every row) per chunk of the double-buffered row tile, and workgroups per CU.  The kernel is bound by
+// dependent latency per tile (row ids -> rows -> product -> gates -> mix), not by bytes or MFMAs, so what pays is MORE
+// workgroups per CU: small chunks (8 KiB per k-step) leave LDS and registers for four (16-bit bags: 128 VGPRs) or three
+// (fp32 bags: 168; at one k-step per chunk they spill) instead of two with four k-steps per chunk (256 VGPRs).  Same box,
+// 202 x 15,000: thirty classes bf16 868 -> 729-737 us, fp32 1,494 -> 1,375-1,396; two classes bf16 108 -> 99, fp32 290 -> 257-265.
+constexpr int F128_ROWS = 128;
+constexpr int f128_kc(int st) { return st == 2 ? 2 : 1; }
+constexpr int f128_wgs(int st) { return st == 2 ? 3 : 4; }
+constexpr int f128_buf(int kc) { return (F128_ROWS / 16) * kc * 1024; }       // one chunk of the workgroup's rows
+constexpr int f128_xb(int kc) { return 2 * f128_buf(kc) > F128_ROWS * (H + 1) * 4 ? 2 * f128_buf(kc) : F128_ROWS * (H + 1) * 4; }
+constexpr int f128_lds(int kc) { return f128_xb(kc) + F128_ROWS * 4 * 4 + 4 * H * 4; }     // + gates + W2: 35.5 KiB
 typedef unsigned __attribute__((ext_vector_type(4))) fu32x4_t;
 template <int OFF>
 __device__ __forceinline__ void fwd_lds16(fu32x4_t& dst, unsigned addr) {
@@ -609,7 +616,8 @@ __device__ __forceinline__ void fwd_touch4(fu32x4_t (&v)[4]) {
 // ST: storage of the bag -- 0 bf16, 1 fp16 (three 16-bit terms of W1 per k-step of 32 columns, v_mfma_f32_16x16x32),
 // 2 fp32 (one fp32 fragment per k-step of 16 columns, four v_mfma_f32_16x16x4_f32)
 template <int ST>
-__global__ __launch_bounds__(256, 2) void meta_forward128_kernel(FwdArgs a) {
+__global__ __launch_bounds__(256, f128_wgs(ST)) void meta_forward128_kernel(FwdArgs a) {
+    constexpr int F128_KC = f128_kc(ST), F128_BUF = f128_buf(F128_KC), F128_XB = f128_xb(F128_KC);
     constexpr bool F16 = ST == 1;
     constexpr int PER = ST == 2 ? 1 : 3;                   // W1 fragments per k-step
     constexpr int ESZ = ST == 2 ? 4 : 2;
@@ -2105,15 +2113,15 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
         // many slides of many selected rows (evaluation): 128 rows per workgroup, rows by LDS-DMA, two workgroups per CU
         static bool attr128 = false;
         if (!attr128) {
-            (void)hipFuncSetAttribute((const void*)meta_forward128_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, F128_LDS);
-            (void)hipFuncSetAttribute((const void*)meta_forward128_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, F128_LDS);
-            (void)hipFuncSetAttribute((const void*)meta_forward128_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, F128_LDS);
+            (void)hipFuncSetAttribute((const void*)meta_forward128_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, f128_lds(f128_kc(0)));
+            (void)hipFuncSetAttribute((const void*)meta_forward128_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, f128_lds(f128_kc(1)));
+            (void)hipFuncSetAttribute((const void*)meta_forward128_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, f128_lds(f128_kc(2)));
             attr128 = true;
         }
         dim3 g128(moc_cdiv(s_bound(B), F128_ROWS), n);
-        if (B->dtype == MOC_F16) meta_forward128_kernel<1><<<g128, 256, F128_LDS, s>>>(a);
-        else if (B->dtype == MOC_BF16) meta_forward128_kernel<0><<<g128, 256, F128_LDS, s>>>(a);
-        else meta_forward128_kernel<2><<<g128, 256, F128_LDS, s>>>(a);
+        if (B->dtype == MOC_F16) meta_forward128_kernel<1><<<g128, 256, f128_lds(f128_kc(1)), s>>>(a);
+        else if (B->dtype == MOC_BF16) meta_forward128_kernel<0><<<g128, 256, f128_lds(f128_kc(0)), s>>>(a);
+        else meta_forward128_kernel<2><<<g128, 256, f128_lds(f128_kc(2)), s>>>(a);
         MOC_CHECK_LAUNCH("moc_meta_forward(128)");
         return MOC_OK;
     }
