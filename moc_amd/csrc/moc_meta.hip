@@ -1675,7 +1675,13 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     // elements (h0 + (l >> 4) * 4 + i, d0 + (l & 15)), i < 4.
     const int NTN = DS / 16;                              // n-tiles (2 or 4)
     const bool has_tile = wave < 4 * NTN;
-    const int h0 = (wave / NTN) * 16, d0 = d_lo + (wave % NTN) * 16;
+    // D = 512: eight tiles, sixteen waves -- waves 8..15 take the SECOND HALF of every chunk's pairs for the same tiles
+    // (twave) and the halves meet in LDS behind the chunk loop (first + second: one fixed association); the chunk's MFMA
+    // phase was 6.1 of the step's 26 us with half of the waves idle
+    const bool ksplit = 4 * NTN <= 8;
+    const int twave = ksplit ? (wave & 7) : wave;
+    const bool in_product = ksplit || has_tile;
+    const int h0 = (twave / NTN) * 16, d0 = d_lo + (twave % NTN) * 16;
     float pw[4], pm[4], pv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1819,8 +1825,11 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
             if (c0 == 0) MOC_STAMP(51);
             __syncthreads();
             if (c0 == 0) MOC_STAMP(52);
-            if (has_tile) {
+            if (in_product) {
                 const int kq = lane >> 4, li = lane & 15, cc = (d0 - d_lo) + li;
+                // this wave's share of the chunk's k-steps: all of them, or (ksplit) the first / second half, cut at a multiple of 4
+                const int half = ((n4 >> 1) + 3) & ~3;
+                const int kb = (ksplit && wave >= 8) ? half : 0, ke = (ksplit && wave < 8) ? half : n4;
                 // eight k = 4 steps at a time: their sixteen LDS reads in flight together (one step at a time the read
                 // latency was exposed 32 times per chunk); storage type decided once, outside
                 auto product = [&](auto kind) {
@@ -1830,8 +1839,8 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
                         else if constexpr (XK == 2) return moc_f16_to_f32(reinterpret_cast<const uint16_t*>(xraw)[(size_t)pp * DS + cc]);
                         else return moc_bf16_to_f32(reinterpret_cast<const uint16_t*>(xraw)[(size_t)pp * DS + cc]);
                     };
-                    int ks = 0;
-                    for (; ks + 32 <= n4; ks += 32) {
+                    int ks = kb;
+                    for (; ks + 32 <= ke; ks += 32) {
                         float av[8], bv[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
@@ -1842,7 +1851,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
 #pragma unroll
                         for (int u = 0; u < 8; ++u) gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], gacc, 0, 0, 0);
                     }
-                    for (; ks < n4; ks += 4) {
+                    for (; ks < ke; ks += 4) {
                         const int pp = ks + kq;
                         gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(dh_s[pp * 64 + ((h0 + li) ^ (kq << 4))], pp < n ? xval(pp) : 0.f, gacc, 0, 0, 0);
                     }
@@ -1855,6 +1864,18 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
         }
     }
     __syncthreads();
+    if (ksplit) {                                          // second halves -> LDS (the chunk buffers are free), first halves add them
+        float* part = reinterpret_cast<float*>(region);    // [8 tiles][4][64]
+        if (wave >= 8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[(twave * 4 + i) * 64 + lane] = gacc[i];
+        }
+        __syncthreads();
+        if (wave < 8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gacc[i] = moc_fadd(gacc[i], part[(twave * 4 + i) * 64 + lane]);
+        }
+    }
     MOC_STAMP(44);
     // ---- small gradients: 16 + 4 (+ 4) sums over the pairs, one per wave, pairs strided over the lanes
     {
