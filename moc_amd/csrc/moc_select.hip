@@ -717,7 +717,7 @@ __global__ __launch_bounds__(1024) void topk_mean_kernel(TopkArgs a) {
 #pragma unroll
             for (int q = 0; q < RK; ++q) {
                 const int i = (int)threadIdx.x + q * 1024;
-                kr[q] = i < n ? keyfn(i) : 0u;
+                { const uint32_t uk = keyfn(i < n ? i : n - 1); kr[q] = i < n ? uk : 0u; }   // (clamped, not branched: the loads of a batch go out together)
                 mx = kr[q] > mx ? kr[q] : mx;
             }
         } else {
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(64 * WT_WAVES) void topk_mean_wave_kernel(TopkArgs 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int i = start + q * 64 + lane;
-                        u[q] = i < n ? keyfn(i) : 0u;
+                        { const uint32_t uk = keyfn(i < n ? i : n - 1); u[q] = i < n ? uk : 0u; }    // (clamped, not branched: the loads of a batch go out together)
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) mx = u[q] > mx ? u[q] : mx;
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(64 * WT_WAVES) void topk_mean_wave_kernel(TopkArgs 
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int i = i0 + q * 64 + lane;
-                        u[q] = i < n ? keyfn(i) : 0u;
+                        { const uint32_t uk = keyfn(i < n ? i : n - 1); u[q] = i < n ? uk : 0u; }    // (clamped, not branched: the loads of a batch go out together)
                     }
 #pragma unroll
                     for (int q = 0; q < 8; ++q) mx = u[q] > mx ? u[q] : mx;
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(64 * WT_WAVES) void topk_mean_wave_kernel(TopkArgs 
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int i = i0 + q * 64 + lane;
-                    u[q] = i < n ? keyfn(i) : 0u;
+                    { const uint32_t uk = keyfn(i < n ? i : n - 1); u[q] = i < n ? uk : 0u; }    // (clamped, not branched: the loads of a batch go out together)
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -1019,6 +1019,7 @@ __global__ __launch_bounds__(64 * WT_WAVES) void topk_mean_wave_kernel(TopkArgs 
         if (a.cnt_out) a.cnt_out[out] = k;
     }
 }
+
 
 }  // namespace
 

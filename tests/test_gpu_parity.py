@@ -1016,3 +1016,4 @@ def test_wave_per_task_topk_gives_the_workgroup_kernels_bits(dev, K, smallest, s
     col = keys[c_i, off[s_i]:off[s_i + 1]]
     order = torch.argsort(-col if not smallest else col, stable=True)[:K]
     assert i_w[s_i, c_i].cpu().tolist() == order.tolist()
+
