@@ -566,19 +566,32 @@ __global__ __launch_bounds__(256) void cand_gather_kernel(CompactArgs a) {
     const int k_lo = blockIdx.y * CAND_COLS, k_hi = min(k_lo + CAND_COLS, 2 * C + 2);
     const float* s = a.stats + base + i;
     float* c = a.cand + base + o;
+    // (every statistic of the thread's columns requested before the first candidate is stored: load -> store per column
+    // in one loop is a round trip per column -- the compiler cannot tell that `cand` and `stats` do not overlap)
+    float v[CAND_COLS];
     if (a.compact) {                                   // s_sigma re-formed from (v, m1, 1/den); m1 and 1/den once per thread
         const float m1 = s[(int64_t)C * a.stride], rden = s[(int64_t)(C + 1) * a.stride];
-        for (int k = k_lo; k < k_hi; ++k) {
-            float v;
-            if (k < C) v = s[(int64_t)k * a.stride];
-            else if (k < 2 * C) v = moc_softmax_from(s[(int64_t)(k - C) * a.stride], m1, rden);
-            else v = s[(int64_t)(k == 2 * C ? C + 2 : C + 4) * a.stride];
-            c[(int64_t)k * a.stride] = v;
+#pragma unroll
+        for (int q = 0; q < CAND_COLS; ++q) {
+            const int k = k_lo + q < k_hi ? k_lo + q : k_hi - 1;
+            const int row = k < C ? k : k < 2 * C ? k - C : (k == 2 * C ? C + 2 : C + 4);
+            v[q] = s[(int64_t)row * a.stride];
+        }
+#pragma unroll
+        for (int q = 0; q < CAND_COLS; ++q) {
+            const int k = k_lo + q;
+            if (k < k_hi) c[(int64_t)k * a.stride] = (k >= C && k < 2 * C) ? moc_softmax_from(v[q], m1, rden) : v[q];
         }
         return;
     }
-    for (int k = k_lo; k < k_hi; ++k)                  // candidate k <- statistic k; the last one is s_beta = max background
-        c[(int64_t)k * a.stride] = s[(int64_t)(k == 2 * C + 1 ? 2 * C + 2 : k) * a.stride];
+#pragma unroll
+    for (int q = 0; q < CAND_COLS; ++q) {              // candidate k <- statistic k; the last one is s_beta = max background
+        const int k = k_lo + q < k_hi ? k_lo + q : k_hi - 1;
+        v[q] = s[(int64_t)(k == 2 * C + 1 ? 2 * C + 2 : k) * a.stride];
+    }
+#pragma unroll
+    for (int q = 0; q < CAND_COLS; ++q)
+        if (k_lo + q < k_hi) c[(int64_t)(k_lo + q) * a.stride] = v[q];
 }
 
 // grid (ceil(max_rows/16), n_slides): copies selected rows (16 B per thread per step)
