@@ -603,7 +603,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(CompactArgs a) {
     for (int s = blockIdx.x * 16 + (threadIdx.x >> 4); s < S; s += gridDim.x * 16) {
         const uint4* src = reinterpret_cast<const uint4*>(a.X + a.sel_row[base + s] * (int64_t)a.row_bytes);
         uint4* dst = reinterpret_cast<uint4*>(a.selected_feat + (base + s) * (int64_t)a.row_bytes);
-        for (int v = threadIdx.x & 15; v < vec_per_row; v += 16) dst[v] = src[v];
+        for (int v0 = threadIdx.x & 15; v0 < vec_per_row; v0 += 64) {     // four pieces requested, then stored (not load -> store four times)
+            uint4 piece[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) piece[u] = src[v0 + 16 * u < vec_per_row ? v0 + 16 * u : v0];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (v0 + 16 * u < vec_per_row) dst[v0 + 16 * u] = piece[u];
+        }
     }
 }
 
@@ -648,7 +655,14 @@ __global__ __launch_bounds__(256) void pack_selected_kernel(PackArgs a) {
     if (s < S && (!a.packed || pref + s < a.out_rows)) {
         const uint4* src = reinterpret_cast<const uint4*>(a.X + a.sel_row[base + s] * (int64_t)a.row_bytes);
         uint4* dst = reinterpret_cast<uint4*>(a.feat_out + (pref + s) * a.row_bytes);
-        for (int v = threadIdx.x & 15; v < vec_per_row; v += 16) dst[v] = src[v];
+        for (int v0 = threadIdx.x & 15; v0 < vec_per_row; v0 += 64) {     // four pieces requested, then stored (not load -> store four times)
+            uint4 piece[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) piece[u] = src[v0 + 16 * u < vec_per_row ? v0 + 16 * u : v0];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (v0 + 16 * u < vec_per_row) dst[v0 + 16 * u] = piece[u];
+        }
     }
     const int nk = 2 * a.C + 2;
     if (a.packed) {
