@@ -528,6 +528,79 @@ def gen_baselines():
     save("baselines", **arrays)
 
 
+# the split semantics of datasets/dataset_generic.py.  The module imports cv2, h5py and
+# utils.utils (torchvision) -- none importable here -- so the dataset classes are taken from the AST like main_moc.py's
+# definitions; constructing them and cutting splits needs pandas only (no item is read from a bag file: with
+# data_dir=None the reference's __getitem__ returns (slide_id, label), dataset_generic.py:412-413, which is exactly the
+# visiting order a shuffle=False DataLoader sees).
+SPLIT_TASKS = {"nsclc": ({"LUAD": 0, "LUSC": 1}, 2), "rcc": ({"KICH": 0, "KIRC": 1, "KIRP": 2}, 3)}
+SPLIT_SHOTS = (1, 2, 4, 8, 16)
+SPLIT_FOLDS = range(5)
+
+
+def load_reference_datasets():
+    from scipy import stats
+    from torch.utils.data import Dataset
+    import pandas as pd
+    ns = dict(torch=torch, np=np, pd=pd, os=os, stats=stats, Dataset=Dataset)
+    return _extract("datasets/dataset_generic.py",
+                    ["Generic_WSI_Classification_Dataset", "Generic_MIL_Dataset", "Generic_MIL_Dataset_ViLa", "Generic_Split"], ns)
+
+
+def gen_splits():
+    """return_splits(from_id=False, csv_path=..., repeat_num=shot*C) (main_moc.py:209-220, :270-281) on the reference's
+    own dataset_csv/{nsclc,rcc}.csv x splits/*_fewshot/{1,2,4,8,16}shots/splits_{0-4}.csv.  Per split: the slides as
+    positions in the slide table (in the split's own order), labels, len(), real_len(); for the train split also the
+    slide visited at every index 0..len-1 (the repeat_num wrap / truncation) and len() after the evaluation loops'
+    `repeat_num = real_len()` (main_moc.py:469-471).  The CSV inputs are copied next to the fixture as data."""
+    import shutil
+    ref = load_reference_datasets()
+    out = {}
+    data_root = os.path.join(HERE, "ref_data")
+    for task, (label_dict, C) in SPLIT_TASKS.items():
+        os.makedirs(os.path.join(data_root, "dataset_csv"), exist_ok=True)
+        shutil.copyfile(os.path.join(REF, "dataset_csv", task + ".csv"), os.path.join(data_root, "dataset_csv", task + ".csv"))
+        ds = ref["Generic_MIL_Dataset"](csv_path=os.path.join(REF, "dataset_csv", task + ".csv"), data_dir=None, shuffle=False,
+                                        seed=1, print_info=False, label_dict=label_dict, patient_strat=False, ignore=[])
+        ds.load_from_h5(True)
+        ds.load_full_path(True)
+        table = ds.slide_data["slide_id"].tolist()
+        pos = {s: i for i, s in enumerate(table)}
+        assert len(pos) == len(table)
+        out[f"{task}/table_ids"] = np.asarray(table)
+        out[f"{task}/table_labels"] = np.asarray(ds.slide_data["label"].tolist(), dtype=np.int64)
+        out[f"{task}/len"] = np.int64(len(ds))
+        for shot in SPLIT_SHOTS:
+            for fold in SPLIT_FOLDS:
+                rel = os.path.join("splits", f"{task}_fewshot", f"{shot}shots", f"splits_{fold}.csv")
+                os.makedirs(os.path.dirname(os.path.join(data_root, rel)), exist_ok=True)
+                shutil.copyfile(os.path.join(REF, rel), os.path.join(data_root, rel))
+                splits = ds.return_splits(from_id=False, csv_path=os.path.join(REF, rel), repeat_num=int(shot) * C)
+                for name, sp in zip(("train", "val", "test"), splits):
+                    key = f"{task}/{shot}/{fold}/{name}"
+                    sp.load_full_path(True)
+                    out[key + "/idx"] = np.asarray([pos[s] for s in sp.slide_data["slide_id"].tolist()], dtype=np.int32)
+                    out[key + "/labels"] = np.asarray(sp.slide_data["label"].tolist(), dtype=np.int64)
+                    out[key + "/len_real"] = np.asarray([len(sp), sp.real_len()], dtype=np.int64)
+                    out[key + "/cls_counts"] = np.asarray([len(c) for c in sp.slide_cls_ids], dtype=np.int64)
+                    # what a shuffle=False loader visits: indices 0 .. len-1 (IndexError ends it, :382-383)
+                    visit = [sp[i] for i in range(len(sp))]
+                    out[key + "/visit"] = np.asarray([pos[v[0]] for v in visit], dtype=np.int32)
+                    assert [int(v[1]) for v in visit] == [int(out[f"{task}/table_labels"][pos[v[0]]]) for v in visit]
+                    try:
+                        sp[len(sp)]
+                        stops = False
+                    except IndexError:
+                        stops = True
+                    out[key + "/stops"] = np.bool_(stops)
+                    if name == "train":           # the evaluation loops' toggle (main_moc.py:469-471, :499)
+                        keep = sp.repeat_num
+                        sp.repeat_num = sp.real_len()
+                        out[key + "/len_eval"] = np.int64(len(sp))
+                        sp.repeat_num = keep
+    save("splits", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]          # e.g. `make_golden.py driver` regenerates one fixture
     ref = load_reference_main()
@@ -546,3 +619,4 @@ if __name__ == "__main__":
     gen_baselines()
     gen_clam()
     gen_clam_hooks()
+    gen_splits()
