@@ -63,17 +63,22 @@ def bottomk_irrel_classifier_pooling(logits, topj, return_indices=False, coords_
         n_fg = len(coords_list)
     else:
         raise ValueError("coords_list should be int or list")
-    if detection:
-        raise NotImplementedError("detection=True is not on the MOC path (main_moc.py:432 never sets it)")
     maxj = min(max(topj), logits.size(0))
     if bottomk is None:
         bottomk = maxj
-    st = row_stats(logits, n_fg)
+    if detection:
+        # :146-149, :161-162 -- ONE foreground column; pooled over two key columns: the foreground logit and the largest
+        # background logit of the rows with the least background mass
+        st = row_stats(logits, 1)
+        bg_key = st[3:4]
+    else:
+        st = row_stats(logits, n_fg)
+        bg_key = st[2 * n_fg + 1:2 * n_fg + 2]
     # rows with the smallest background mass, then their foreground logits ranked per class
-    _, low, _ = engine.topk_mean(st[2 * n_fg + 1:2 * n_fg + 2], st[2 * n_fg + 1:2 * n_fg + 2], bottomk,
-                                 smallest=True, want_idx=True)
+    _, low, _ = engine.topk_mean(bg_key, bg_key, bottomk, smallest=True, want_idx=True)
     bg_rows = low[0, 0].to(torch.int64)
-    fg = st[:n_fg].index_select(1, bg_rows).contiguous()
+    fg_src = torch.stack([st[0], st[4]]) if detection else st[:n_fg]
+    fg = fg_src.index_select(1, bg_rows).contiguous()
     out = _pool(fg, fg, topj, maxj, return_indices=return_indices)
     if return_indices:
         return out[0], out[1], bg_rows[out[2]]

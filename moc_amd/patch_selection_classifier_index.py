@@ -65,16 +65,21 @@ def index_bottomk_irrel_classifier(logits, topj, n_classes, bottomk=None, detect
     """utils/patch_selection_classifier_index.py:53-87"""
     assert n_classes is not None, "coords_list should be provided"
     assert logits.size(1) > n_classes, "logits should have more bg classes"
-    if detection:
-        raise NotImplementedError("detection=True is not on the MOC path (main_moc.py:351 never sets it)")
     maxj = min(max(topj), logits.size(0))
     if bottomk is None:
         bottomk = maxj
-    st = row_stats(logits, n_classes)
     if bottomk > logits.size(0):
         print("heyhey small", bottomk, logits.size(0))
         bottomk = logits.size(0)
-    bg_rows = _ranked(st[2 * n_classes + 1:2 * n_classes + 2], bottomk, smallest=True)[:, 0]   # [bottomk]
-    fg = st[:n_classes].index_select(1, bg_rows)                                             # [C, bottomk]
-    order = _ranked(fg, min(maxj, bottomk))                                                   # [maxj, C]
+    if detection:
+        # :65-68, :83-84 -- ONE foreground column, every other column background; the candidate rows are ranked by the
+        # foreground logit AND by their largest background logit: two key columns out of the same statistics
+        st = row_stats(logits, 1)                              # logits[:, 0] | softmax | gap | sum(bg) | max(bg)
+        bg_rows = _ranked(st[3:4], bottomk, smallest=True)[:, 0]
+        fg = torch.stack([st[0], st[4]]).index_select(1, bg_rows).contiguous()
+    else:
+        st = row_stats(logits, n_classes)
+        bg_rows = _ranked(st[2 * n_classes + 1:2 * n_classes + 2], bottomk, smallest=True)[:, 0]   # [bottomk]
+        fg = st[:n_classes].index_select(1, bg_rows)                                             # [C, bottomk]
+    order = _ranked(fg, min(maxj, bottomk))                                                       # [maxj, C]
     return bg_rows[order]

@@ -69,13 +69,27 @@ def sel_gap(logits, topj):
     return rep.topk(_cap(topj, logits.size(0)), 0, True, True)[1]
 
 
-def sel_low_background(logits_ext, topj, n_classes):
+def _low_background_parts(logits_ext, n_fg, detection):
+    """(foreground columns, background mass, extra key column) -- index.py:65-71 / classifier.py:146-152.
+    detection=True: ONE foreground column (column 0), every other column is background, and the rows are also ranked by
+    their largest background logit (appended as a second key column, index.py:83-84)."""
+    if detection:
+        bg = logits_ext[:, 1:]
+        return logits_ext[:, 0].unsqueeze(1), bg.sum(dim=1), torch.topk(bg, 1, dim=1)[0][:, 0]
+    return logits_ext[:, :n_fg], logits_ext[:, n_fg:].sum(dim=1), None
+
+
+def sel_low_background(logits_ext, topj, n_classes, bottomk=None, detection=False):
     assert n_classes is not None, "coords_list should be provided"
     assert logits_ext.size(1) > n_classes, "logits should have more bg classes"
     maxj = _cap(topj, logits_ext.size(0))
-    bg_sum = logits_ext[:, n_classes:].sum(dim=1)
-    low = bg_sum.topk(maxj, 0, False, True)[1]          # smallest background mass
-    order = logits_ext[:, :n_classes][low].topk(maxj, 0, True, True)[1]
+    bottomk = maxj if bottomk is None else min(bottomk, logits_ext.size(0))
+    fg, bg_sum, extra = _low_background_parts(logits_ext, n_classes, detection)
+    low = bg_sum.topk(bottomk, 0, False, True)[1]       # smallest background mass
+    keys = fg[low]
+    if extra is not None:
+        keys = torch.cat([keys, extra[low].unsqueeze(1)], dim=1)
+    order = keys.topk(maxj, 0, True, True)[1]
     return low[order]
 
 
@@ -111,12 +125,16 @@ def pool_gap(logits, topj, return_indices=False):
     return (*out, idx) if return_indices else out
 
 
-def pool_low_background(logits_ext, topj, n_classes, return_indices=False):
+def pool_low_background(logits_ext, topj, n_classes, return_indices=False, bottomk=None, detection=False):
     assert logits_ext.size(1) > n_classes, "logits should have more bg classes"
     maxj = _cap(topj, logits_ext.size(0))
-    bg_sum = logits_ext[:, n_classes:].sum(dim=1)
-    low = bg_sum.topk(maxj, 0, False, True)[1]
-    fg_values, order = logits_ext[:, :n_classes][low].topk(maxj, 0, True, True)
+    bottomk = maxj if bottomk is None else bottomk
+    fg, bg_sum, extra = _low_background_parts(logits_ext, n_classes, detection)
+    low = bg_sum.topk(bottomk, 0, False, True)[1]
+    keys = fg[low]
+    if extra is not None:
+        keys = torch.cat([keys, extra[low].unsqueeze(1)], dim=1)
+    fg_values, order = keys.topk(maxj, 0, True, True)
     out = _finish_pool(fg_values, topj, maxj)
     return (*out, low[order]) if return_indices else out
 

@@ -191,6 +191,30 @@ def gen_pooling():
     save("pooling", **out)
 
 
+def gen_detection():
+    """`detection=True` of the two low-background helpers (index.py:65-68, :83-84; classifier.py:146-149, :161-162): one
+    foreground column, rows also ranked by their largest background logit; with and without an explicit bottomk."""
+    out, cases = {}, []
+    cid = 0
+    for N, Ct, j, bottomk in ((40, 5, 10, None), (1000, 6, 10, None), (1000, 6, 100, 300), (3000, 34, 400, None), (7, 3, 10, None)):
+        seed = 9500 + cid
+        W, We = synth.make_bank(seed, 512, Ct - 4 if Ct > 5 else 2)
+        x = synth.make_bag(seed + 500, N, 512, We, We.size(1) - 4 if Ct > 5 else 2, label=0)
+        lge = (x @ We)[:, :Ct].contiguous()
+        kw = {} if bottomk is None else {"bottomk": bottomk}
+        out[f"c{cid}_logits_ext"] = lge.numpy()
+        out[f"c{cid}_idx"] = i32(index_bottomk_irrel_classifier(lge, [j], 1, detection=True, **kw))
+        p, pooled, idx = bottomk_irrel_classifier_pooling(lge, [1, j], return_indices=True, coords_list=1, detection=True, **kw)
+        out[f"c{cid}_pool_idx"] = i32(idx)
+        out[f"c{cid}_pooled_1"] = pooled[1].numpy()
+        out[f"c{cid}_pooled_j"] = pooled[j].numpy()
+        out[f"c{cid}_pred_j"] = i32(p[j])
+        cases.append((cid, N, Ct, j, -1 if bottomk is None else bottomk, seed))
+        cid += 1
+    out["cases"] = np.array(cases, dtype=np.int64)
+    save("detection", **out)
+
+
 def _args(C, j, K, discard=()):
     return types.SimpleNamespace(disable_tqdm=True, n_classes=C, topj=j, topk=K,
                                  discard_classifiers=list(discard), pretrain="conch",
@@ -620,3 +644,4 @@ if __name__ == "__main__":
     gen_clam()
     gen_clam_hooks()
     gen_splits()
+    gen_detection()

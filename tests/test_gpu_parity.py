@@ -314,6 +314,25 @@ def test_index_functions_match_reference_fixtures(dev):
                 assert bool((v[1:] <= v[:-1]).all())
 
 
+def test_detection_mode_matches_reference_fixtures(dev):
+    """detection=True (index.py:65-68, :83-84; classifier.py:146-149, :161-162): one foreground column, the rows with the
+    least background mass ranked by the foreground logit and by their largest background logit."""
+    from moc_amd import patch_selection_classifier as P, patch_selection_classifier_index as I
+    g = H.golden("detection")
+    for cid, N, Ct, j, bottomk, seed in g["cases"]:
+        lge = torch.from_numpy(g[f"c{cid}_logits_ext"]).to(dev)
+        kw = {} if bottomk < 0 else {"bottomk": int(bottomk)}
+        idx = I.index_bottomk_irrel_classifier(lge, [int(j)], 1, detection=True, **kw)
+        assert idx.dtype == torch.int64 and tuple(idx.shape) == g[f"c{cid}_idx"].shape == (min(int(j), int(N)), 2)
+        assert np.array_equal(idx.cpu().numpy().astype(np.int32), g[f"c{cid}_idx"]), cid
+        preds, pooled, pidx = P.bottomk_irrel_classifier_pooling(lge, [1, int(j)], return_indices=True, coords_list=1,
+                                                                 detection=True, **kw)
+        assert np.array_equal(pidx.cpu().numpy().astype(np.int32), g[f"c{cid}_pool_idx"]), cid
+        np.testing.assert_allclose(pooled[1].cpu().numpy(), g[f"c{cid}_pooled_1"], atol=1e-5, rtol=0)
+        np.testing.assert_allclose(pooled[int(j)].cpu().numpy(), g[f"c{cid}_pooled_j"], atol=1e-5, rtol=0)
+        assert np.array_equal(preds[int(j)].cpu().numpy().astype(np.int32), g[f"c{cid}_pred_j"])
+
+
 def test_topk_mean_edges(dev):
     E = _engine()
     v = torch.tensor([[3.0, 1.0, 2.0, 2.0, 5.0]], device=dev)

@@ -69,6 +69,21 @@ def test_pooling_matches_reference():
         assert np.array_equal(preds[10].numpy().astype(np.int32), g[f"c{cid}_topj_pred"])
 
 
+def test_detection_mode_matches_reference():
+    """detection=True of the low-background helpers (index.py:65-68, :83-84; classifier.py:146-149, :161-162)."""
+    g = H.golden("detection")
+    for cid, N, Ct, j, bottomk, seed in g["cases"]:
+        lge = torch.from_numpy(g[f"c{cid}_logits_ext"])
+        kw = {} if bottomk < 0 else {"bottomk": int(bottomk)}
+        idx = O.sel_low_background(lge, [int(j)], 1, detection=True, **kw)
+        assert np.array_equal(idx.numpy().astype(np.int32), g[f"c{cid}_idx"])
+        preds, pooled, pidx = O.pool_low_background(lge, [1, int(j)], 1, return_indices=True, detection=True, **kw)
+        assert np.array_equal(pidx.numpy().astype(np.int32), g[f"c{cid}_pool_idx"])
+        np.testing.assert_allclose(pooled[1].numpy(), g[f"c{cid}_pooled_1"], atol=1e-6)
+        np.testing.assert_allclose(pooled[int(j)].numpy(), g[f"c{cid}_pooled_j"], atol=1e-6)
+        assert np.array_equal(preds[int(j)].numpy().astype(np.int32), g[f"c{cid}_pred_j"])
+
+
 def test_train_steps_match_reference():
     g = H.golden("train")
     for cid, ns, N, C, j, K, dmask, seed in g["cases"]:
