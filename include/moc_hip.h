@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 15
+#define MOC_ABI_VERSION 16
 
 enum { MOC_TICKET_QUEUES = 64, MOC_TICKET_STRIDE = 64,     /* moc_batch_t.tile_ticket: counters, int32 words between them */
        MOC_TICKET_WORDS = (64 + 8) * 64 };
@@ -270,6 +270,15 @@ int moc_ce_loss(const float* pooled, const int64_t* labels, int n, int C, float*
  * M->g_*.  The data-parallel step all-reduces them and calls moc_adam_step. */
 int moc_train_grad(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws,
                    const int64_t* labels, int slide, uint32_t use_bits, moc_stream_t stream);
+
+/* a14 for a caller-written loop (main_moc.py:390-410 kept as it is around slide_process): the backward of
+ * `lambdas = model(selected_feat)` given d loss / d lambdas.  X [S, D] are the rows the forward ran on (storage `dtype`),
+ * H1 [S, H] / gates [S, 4] what moc_meta_forward left for them, grad_gates [S, 4] autograd's gradient (rows of zeros
+ * carry nothing and are skipped).  Writes (does not accumulate) g_W1 [H, D], g_b1 [H], g_W2 [4, H], g_b2 [4].
+ * Scratch, all device: pair_dz [S, 4], pair_dh [S, H], pair_row [S], n_pair [1]. */
+int moc_senet_backward(const void* X, int dtype, int64_t S, int D, const float* H1, const float* gates,
+                       const float* grad_gates, const float* W2, float* g_W1, float* g_b1, float* g_W2, float* g_b2,
+                       float* pair_dz, float* pair_dh, int64_t* pair_row, int32_t* n_pair, moc_stream_t stream);
 
 /* a15: one Adam step (coupled L2) from M->g_* scaled by grad_scale; uses step = M->step+1. */
 int moc_adam_step(const moc_meta_t* M, float grad_scale, moc_stream_t stream);

