@@ -101,9 +101,9 @@ def choose_reserved_slots(slots, n):
     dealt round-robin over its shader engines / arrays (HW_ID[15:12]), the highest CU id of each first.  Pure."""
     n = int(n)
     assert n > 0, f"{n} reserved compute units"
-    # a smaller part or partition (CPX / DPX, HSA_CU_MASK), or a census that saw less: never more than a quarter of what
-    # exists (64 of 256 is the measured optimum); an empty result tells the caller to keep the static whole-chip walk
-    n = min(n, len(slots) // 4)
+    # a smaller part or partition (CPX / DPX, HSA_CU_MASK), or a census that saw less: never more than half of what
+    # exists; an empty result tells the caller to keep the static whole-chip walk
+    n = min(n, len(slots) // 2)
     if n <= 0:
         return []
     xccs = sorted({x for x, _ in slots})
