@@ -38,7 +38,7 @@ def test_irregular_harvest_and_bitmap():
     for x, s in chosen:
         bit = x * 256 + s
         assert words[bit >> 5] >> (bit & 31) & 1
-    assert len(E.choose_reserved_slots(slots, len(slots))) == len(slots) // 2     # clamped to half of the chip
+    assert len(slots) // 2 - 8 <= len(E.choose_reserved_slots(slots, len(slots))) <= len(slots) // 2     # clamped to half of the chip (of every XCD)
     with pytest.raises(AssertionError):
         E.choose_reserved_slots(slots, 0)
 
