@@ -158,11 +158,19 @@ typedef struct moc_meta_ws {
                                             the other (may be NULL: three-launch step is used)      */
     int64_t* pair_row;  /* [C*topk]                                                          */
     int32_t* n_pair;    /* [1]                                                               */
+    /* round 4: tile records (nullable).  Scratch of moc_tile_ws_bytes(total_rows, n_slides, C) bytes, 16-byte aligned:
+     * the forward of a training step leaves, per 16-row tile and class, the tile's four largest mixed scores with
+     * their rows' ids, gates and candidate scores; the one-launch step then pools among those records instead of
+     * re-reading and ranking every mixed score (exactness checked in the kernel, full scores as the fall-back).
+     * NULL: the round-3 step. */
+    void*    tile_ws;
+    int64_t  tile_ws_bytes;
 } moc_meta_ws_t;
 
 int         moc_version(void);
 const char* moc_last_error(void);
 size_t      moc_w1_image_bytes(int D, int dtype);
+size_t      moc_tile_ws_bytes(int64_t total_rows, int n_slides, int C);   /* moc_meta_ws_t.tile_ws */
 
 /* ---- classifier bank ------------------------------------------------------
  * Re-lays [zeroshot_weights | zeroshot_weights_ext[:, C:]] (main_moc.py:336-337:

@@ -52,7 +52,7 @@ class MocMeta(C.Structure):
 
 class MocMetaWs(C.Structure):
     _fields_ = [(n, _p) for n in ("H1", "gates", "mixed", "pooled", "topk_idx", "topk_cnt",
-                                  "loss", "pred", "pair_dh", "W2_alt", "pair_row", "n_pair")]
+                                  "loss", "pred", "pair_dh", "W2_alt", "pair_row", "n_pair", "tile_ws")] + [("tile_ws_bytes", C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/moc_hip.h declares
@@ -62,6 +62,7 @@ SIGNATURES = {
     "moc_last_error": (C.c_char_p, []),
     "moc_bank_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "moc_w1_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "moc_tile_ws_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "moc_prepare_bank": (C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _p, _p]),
     "moc_host_draw_masks": (C.c_int64, [_p, C.c_int64, C.c_int64, _p]),
     "moc_host_max_kept": (C.c_int64, [_p, _p, C.c_int]),

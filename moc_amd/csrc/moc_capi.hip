@@ -27,6 +27,9 @@ __device__ unsigned long long g_moc_stamps[128];
 extern "C" int moc_debug_stamps(unsigned long long* host_out, int n) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_moc_stamps), sizeof(unsigned long long) * n);
 }
+extern "C" int moc_debug_stamps_set(const unsigned long long* host_in, int n) {      // (MOC_STAMP_MAX / _MIN slots start from here)
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_moc_stamps), host_in, sizeof(unsigned long long) * n);
+}
 #endif
 
 // ---- which compute units are there (include/moc_hip.h: compute units kept free of the score pass) ---------------

@@ -196,7 +196,18 @@ extern __device__ unsigned long long g_moc_stamps[128];
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
         MOC_STAMP(id);                                                                         \
     } while (0)
+// the LATEST time any workgroup of the launch passes here (thread 0 of every workgroup; the host clears the slot)
+#define MOC_STAMP_MAX(id)                                                                      \
+    do {                                                                                       \
+        if (threadIdx.x == 0) atomicMax(&g_moc_stamps[id], (unsigned long long)wall_clock64());  \
+    } while (0)
+#define MOC_STAMP_MIN(id)                                                                      \
+    do {                                                                                       \
+        if (threadIdx.x == 0) atomicMin(&g_moc_stamps[id], (unsigned long long)wall_clock64());  \
+    } while (0)
 #else
 #define MOC_STAMP(id) do { } while (0)
 #define MOC_STAMP_DRAIN(id) do { } while (0)
+#define MOC_STAMP_MAX(id) do { } while (0)
+#define MOC_STAMP_MIN(id) do { } while (0)
 #endif

@@ -52,6 +52,70 @@ __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float 
     p = moc_fadd(p, moc_fdiv(moc_fmul(k.neg_step_size, m), denom));
 }
 
+// ------------------------------------------------------------------ tile records (round 4)
+// The step kernel used to request and rank ALL S x C mixed scores of the slide the forward had just written -- a memory
+// round trip of sixteen loads per thread, then the candidate search over them on sixteen waves of one CU.  The forward's
+// workgroups now leave, per 16-row tile and class, the tile's TILE_R largest scores as RECORDS -- the key (score | ~row),
+// the row's id in the bag, its four gates and its four candidate scores: everything the backward needs of a pooled row
+// except its hidden activations and the row itself -- plus rho = the key of the tile's (TILE_R + 1)-th largest score.
+// The step kernel reads a class's ceil(S / 16) x TILE_R keys with ONE wave, finds a lower bound T0 of the K-th largest
+// score (the K-th largest of sixteen group maxima: group g = the tiles g, g + 16, ...) and pools among the records >= T0.
+// That is EXACT whenever every score >= T0 is a record, i.e. when no tile holds more than TILE_R of them: rho < T0 for
+// every tile -- checked; otherwise (and for more than 64 candidates) the kernel falls back to the full scores, which the
+// forward still writes.  Same rows, same (value desc, row asc) order, same sum: same bits.
+constexpr int TILE_R = 4;
+constexpr int MOC_TILE_PATH_RECORDS = 1000001, MOC_TILE_PATH_FULL = 1000002;   // left in ws->n_pair[0] by the tile-record step
+struct TileWs {
+    float4* lam;                 // [slots] gates of the record's row
+    float4* sc;                  // [slots] its candidate scores s_p[c], s_sigma[c], s_delta, s_beta
+    unsigned long long* key;     // [slots] (moc_key_desc(score) << 32) | ~row; high word 0: empty
+    int64_t* rid;                // [slots] sel_row of the row
+    uint32_t* rho;               // [slots / TILE_R] high word of the (TILE_R + 1)-th largest key of the (tile, class); 0: none
+};
+// Slide b owns the slots from slot0 = ((row_off[b] >> 4) + b) * C * TILE_R on: C * cap * TILE_R of them, cap = ceil(rows of
+// the slide / 16), class-major: record r of (tile x, class c) is slot0 + (c * cap + x) * TILE_R + r (a class's records are
+// contiguous: one wave reads them); rho of (x, c) is entry slot0 / TILE_R + c * cap + x.
+__host__ __device__ inline int64_t tile_slots(int64_t total_rows, int n_slides, int C) {
+    return ((total_rows >> 4) + n_slides + 2) * (int64_t)C * TILE_R;
+}
+__host__ __device__ inline TileWs tile_carve(void* p, int64_t ns) {
+    TileWs T;
+    unsigned char* q = (unsigned char*)p;
+    T.lam = (float4*)q; q += ns * 16;
+    T.sc = (float4*)q; q += ns * 16;
+    T.key = (unsigned long long*)q; q += ns * 8;
+    T.rid = (int64_t*)q; q += ns * 8;
+    T.rho = (uint32_t*)q;
+    return T;
+}
+__host__ __device__ inline size_t tile_bytes(int64_t ns) { return (size_t)ns * 48 + (size_t)(ns / TILE_R) * 4 + 16; }
+
+// Epilogue of a forward workgroup: thread t = class * 16 + row holds the mixed score v of (row0 + row, class); the 16 rows
+// of a class are 16 consecutive lanes (one DPP row).  Every lane ranks its key among the row's sixteen by fifteen row
+// rotations (keys are unique: absent rows carry (0 | ~row)), ranks 0 .. TILE_R-1 write their record, rank TILE_R writes rho.
+__device__ __forceinline__ void tile_emit(const TileWs& T, int64_t tc, bool ok, float v, int row, int64_t rid, float4 lam, float4 sc) {
+    const unsigned hi = ok ? moc_key_desc(v) : 0u, lo = ~(unsigned)row;
+    int rank = 0;
+#define MOC_ROR(n)                                                                                              \
+    {                                                                                                           \
+        const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x120 + n, 0xf, 0xf, false);     \
+        const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x120 + n, 0xf, 0xf, false);     \
+        rank += (ohi > hi || (ohi == hi && olo > lo)) ? 1 : 0;                                                  \
+    }
+    MOC_ROR(1) MOC_ROR(2) MOC_ROR(3) MOC_ROR(4) MOC_ROR(5) MOC_ROR(6) MOC_ROR(7) MOC_ROR(8)
+    MOC_ROR(9) MOC_ROR(10) MOC_ROR(11) MOC_ROR(12) MOC_ROR(13) MOC_ROR(14) MOC_ROR(15)
+#undef MOC_ROR
+    if (rank < TILE_R) {
+        const int64_t slot = tc * TILE_R + rank;
+        T.key[slot] = ((unsigned long long)hi << 32) | lo;
+        T.rid[slot] = rid;
+        T.lam[slot] = lam;
+        T.sc[slot] = sc;
+    } else if (rank == TILE_R) {
+        T.rho[tc] = hi;
+    }
+}
+
 // ------------------------------------------------------------------ forward
 struct FwdArgs {
     const unsigned char* X;
@@ -73,6 +137,10 @@ struct FwdArgs {
     int cand_mode;
     const float* stats;
     const int32_t* sel_idx;
+    // tile records for the step kernel (training step of ONE slide, base_host >= 0): tile_on != 0
+    TileWs tile;
+    int tile_on, tile_cap;          // tile_cap = ceil(rows of the slide / 16)
+    int64_t tile_slot0;             // first slot of the slide's region
 };
 
 // the row of a selected slot o in whichever array holds its candidate scores: column k of it is ptr[k * stride]
@@ -177,6 +245,8 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
     const float w2_pre = a.W2[threadIdx.x & 255];
     const float bias = a.b1[wave * 16 + (lane & 15)];
     const float b2_pre = a.b2[threadIdx.x & 3];
+    int64_t rid_e = 0;                                               // tile records: the bag row of this thread's (row, class)
+    if (a.tile_on) rid_e = a.sel_row[base + min(row0 + (int)(threadIdx.x & 15), S - 1)];
     // The 16 x D tile of x goes through LDS once per workgroup: wave w fetches rows 4w..4w+3 with
     // whole-row contiguous loads (UB bytes per row per unit) and stores 16-B chunk c of row r at
     // chunk c ^ (r & 15), so that the A-fragment reads (lane l: row l&15, chunk 4*kk + (l>>4)) hit
@@ -303,6 +373,18 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
         if (a.use_bits & 8u) v = moc_fadd(v, moc_fmul(Gs[r][3], s3));
         a.mixed[(int64_t)c * a.stride + base + row0 + r] = v;
     }
+    if (a.tile_on && threadIdx.x < 16 * C) {                         // (C <= 16 here: one element per thread)
+        const int r = threadIdx.x & 15, c = threadIdx.x >> 4;
+        const bool ok = row0 + r < S;
+        float v = 0.f;
+        if (a.use_bits & 1u) v = moc_fadd(v, moc_fmul(Gs[r][0], pre_c[0]));
+        if (a.use_bits & 2u) v = moc_fadd(v, moc_fmul(Gs[r][1], pre_c[1]));
+        if (a.use_bits & 4u) v = moc_fadd(v, moc_fmul(Gs[r][2], pre_c[2]));
+        if (a.use_bits & 8u) v = moc_fadd(v, moc_fmul(Gs[r][3], pre_c[3]));
+        const float4 lam4 = {Gs[r][0], Gs[r][1], Gs[r][2], Gs[r][3]};
+        const float4 sc4 = {pre_c[0], pre_c[1], pre_c[2], pre_c[3]};
+        tile_emit(a.tile, a.tile_slot0 / TILE_R + (int64_t)c * a.tile_cap + blockIdx.x, ok, v, row0 + r, rid_e, lam4, sc4);
+    }
     MOC_STAMP(2);
 }
 
@@ -341,6 +423,8 @@ __global__ __launch_bounds__(1024) void meta_forward_ksplit_kernel(FwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int ht = wave & 3, kq = wave >> 2;
     MOC_STAMP(0);
+    MOC_STAMP_MIN(31);                                      // (diagnostic: the first workgroup of the launch to start)
+    MOC_STAMP_MAX(32);                                      // (... and the last one to start)
     // this wave's row, whole: the row id is one scalar load, the row D / 256 loads of 1 KiB per wave
     constexpr int64_t row_bytes = (int64_t)D * 4;
     constexpr int cpl = DQ;                                  // 16-byte chunks per lane
@@ -391,6 +475,8 @@ __global__ __launch_bounds__(1024) void meta_forward_ksplit_kernel(FwdArgs a) {
     const float w2_pre = a.W2[t & 255];
     const float bias = a.b1[t & 63];
     const float b2_pre = a.b2[t & 3];
+    int64_t rid_e = 0;                                       // tile records: the bag row of this thread's (row, class)
+    if (a.tile_on) rid_e = a.sel_row[base + min(row0 + er, S - 1)];
     __builtin_amdgcn_sched_barrier(0);                       // (hipcc otherwise sinks these requests below the chain)
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     {
@@ -417,6 +503,7 @@ __global__ __launch_bounds__(1024) void meta_forward_ksplit_kernel(FwdArgs a) {
         if (t < 4 * H) W2s[t] = w2_pre;
     }
     __syncthreads();
+    MOC_STAMP(7);
     {   // thread = (row t >> 6, hidden unit t & 63)
         const int r = t >> 6, h = t & 63;
         const float* pp = part + (size_t)r * FKS_PSTR + h;
@@ -426,6 +513,7 @@ __global__ __launch_bounds__(1024) void meta_forward_ksplit_kernel(FwdArgs a) {
         if (a.H1 && row0 + r < S) a.H1[(base + row0 + r) * H + h] = hv;      // needed by the backward pass only
     }
     __syncthreads();
+    MOC_STAMP(8);
     if (t < 64) {
         const int r = t >> 2, i = t & 3;
         float z = 0.f;
@@ -436,15 +524,22 @@ __global__ __launch_bounds__(1024) void meta_forward_ksplit_kernel(FwdArgs a) {
         if (a.gates && row0 + r < S) a.gates[(base + row0 + r) * 4 + i] = g;
     }
     __syncthreads();
-    if (e_ok) {
+    MOC_STAMP(9);
+    if (ec < C) {                                            // (uniform over a class's sixteen lanes)
         float v = 0.f;   // 0 + x == x exactly, so this is the reference's running sum in both modes
         if (a.use_bits & 1u) v = moc_fadd(v, moc_fmul(Gs[er][0], pre_c[0]));
         if (a.use_bits & 2u) v = moc_fadd(v, moc_fmul(Gs[er][1], pre_c[1]));
         if (a.use_bits & 4u) v = moc_fadd(v, moc_fmul(Gs[er][2], pre_c[2]));
         if (a.use_bits & 8u) v = moc_fadd(v, moc_fmul(Gs[er][3], pre_c[3]));
-        a.mixed[(int64_t)ec * a.stride + base + row0 + er] = v;
+        if (e_ok) a.mixed[(int64_t)ec * a.stride + base + row0 + er] = v;
+        if (a.tile_on) {
+            const float4 lam4 = {Gs[er][0], Gs[er][1], Gs[er][2], Gs[er][3]};
+            const float4 sc4 = {pre_c[0], pre_c[1], pre_c[2], pre_c[3]};
+            tile_emit(a.tile, a.tile_slot0 / TILE_R + (int64_t)ec * a.tile_cap + blockIdx.x, e_ok, v, row0 + er, rid_e, lam4, sc4);
+        }
     }
     MOC_STAMP(2);
+    MOC_STAMP_MAX(30);                                      // (diagnostic: the last workgroup of the launch to get here)
 }
 
 // Many slides at once (evaluation): 30,000 sixteen-row workgroups each re-read the whole 192 KiB W1 image and
@@ -1021,9 +1116,9 @@ struct PoolLds {
 // CE_OFF = widest xor offset (8: C <= 16, 32: C <= 64)
 template <int CE_OFF>
 __device__ __forceinline__ void ce_wave0(const FinishArgs& a, int b, int C, int y, const float* pooled_s, float* dpool,
-                                         bool write_out) {
+                                         bool write_out, int which_wave = 0) {
     const int lane = threadIdx.x & 63;
-    if ((threadIdx.x >> 6) != 0) return;
+    if ((int)(threadIdx.x >> 6) != which_wave) return;
     const float xv = lane < C ? pooled_s[lane] : -INFINITY;
     float mx = xv;
     int arg = lane < C ? lane : 0x7fffffff;
@@ -1629,6 +1724,477 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
     MOC_STAMP(18);
 }
 
+// ---- the one-launch step over the forward's tile records (round 4) ----------------------------------------------
+// Same job as pool_w1_step_kernel -- pooling, loss, backward, the whole Adam step in one launch, every workgroup
+// repeating the pooling for itself -- restructured around what the phase stamps of round 4 showed (profiles/NOTES.md):
+// the step is a chain of dependent memory round trips and of dependent instructions; neither gets shorter by adding
+// threads, only by taking round trips and instructions out of the chain.
+//  * A workgroup is FOUR waves and owns 256 columns of ONE hidden unit of W1 (grid D / 256 x H: 128 workgroups at
+//    D = 512); the workgroups of column block 0 also own b1[h] and W2[:, h], workgroup (0, 0) b2.  Every sum over the
+//    pairs runs in the same order as in pool_w1_step_kernel: the same bits.
+//  * The kernel's arguments are its own compact struct, ordered by first use, and every cache line of them is touched
+//    at the top in ONE wait: the general step's 700 bytes of arguments were five scalar-cache misses one after the other
+//    in front of the first load.
+//  * The pooling of class c is ONE wave's business from the first load to the pooled rows, with no workgroup barrier in
+//    between: it reads the class's tile records (above; VQ keys per lane), forms the sixteen group maxima in registers
+//    (32-bit score keys: quad maxima, one ds_bpermute, fifteen row rotations for the ranks), lists the records >= T0,
+//    requests the candidates' row ids / gates / candidate scores -- one round trip that the ranking loop hides -- and
+//    leaves the pooled rows' operands in LDS.  No second gather round for them.
+//  * Then ONE more round trip: the pairs' 256-column row pieces (three waves), their hidden activation of unit h,
+//    while the fourth wave does the cross entropy; the parameters this workgroup steps were requested at the top.
+// Falls back to the full scores inside the kernel when the records cannot prove exactness.
+struct TileStepArgs {
+    // ---- first cache line: what the first loads need
+    const unsigned long long* tkey;
+    const uint32_t* trho;
+    int64_t slot0;
+    int cap, ntile_bound, C, K, D, slide0, PS_CAP, xdt;
+    const int32_t* n_sel;
+    const int64_t* labels;
+    // ---- what this thread steps
+    float *W1, *m_W1, *v_W1;
+    const float* W2;
+    float *b1, *m_b1, *v_b1, *b2, *m_b2, *v_b2, *m_W2, *v_W2;
+    int64_t base;
+    AdamCoef adam;
+    const AdamCoef* adam_tab;       // graph replay: coefficients adam_tab[adam_ctr[0] + adam_pos]
+    const int32_t* adam_ctr;
+    int adam_pos, apply_adam;
+    uint32_t use_bits;
+    int img_dt;
+    // ---- the candidates' operands, round trip 2
+    const int64_t* trid;
+    const float4* tlam;
+    const float4* tsc;
+    const float* H1;
+    const unsigned char* X;
+    // ---- outputs
+    float* pooled_out;
+    int32_t* topk_idx_out;
+    int32_t* topk_cnt_out;
+    float* loss;
+    int32_t* pred;
+    int32_t* n_pair;
+    unsigned char* W1img;
+    float* W2out;
+    float *g_W1, *g_b1, *g_W2, *g_b2;
+    // ---- fall-back
+    const float* mixed_in;
+    const float* cand;
+    const float* gates;
+    const int64_t* sel_row;
+    int64_t stride;
+};
+
+template <int VQ>
+__global__ __launch_bounds__(256) void pool_w1_step_tiles_kernel(TileStepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    {   // every cache line of the arguments, requested side by side, one wait
+        static_assert(sizeof(TileStepArgs) <= 512, "TileStepArgs outgrew the lines touched here");
+#if defined(__HIP_DEVICE_COMPILE__)
+        auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+        unsigned k0, k1, k2, k3, k4, k5, k6, k7;
+        asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\t"
+                     "s_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\t"
+                     "s_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3), "=&s"(k4), "=&s"(k5), "=&s"(k6), "=&s"(k7)
+                     : "s"(ka) : "memory");
+#endif
+    }
+    const int b = a.slide0, C = a.C, K = a.K, D = a.D, PS_CAP = a.PS_CAP;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int cb = blockIdx.x, h = blockIdx.y;
+    const bool wg0 = cb == 0 && h == 0;
+    constexpr int CL = 64;                                                            // candidates per class
+    MOC_STAMP(10);
+    MOC_STAMP_MIN(33);
+    MOC_STAMP_MAX(34);
+    const int64_t base = a.base, slot0 = a.slot0;
+    const int cap = a.cap, ntile_bound = a.ntile_bound;
+    // ---- round trip 1, requested before anything else: the keys of this wave's first class (wave w: classes w, w + 4, ...)
+    unsigned long long key[VQ];
+    uint32_t rho[VQ / 4];
+#define MOC_TILE_KEYS(c)                                                                                              \
+    {                                                                                                                 \
+        const int64_t s_c_ = slot0 + (int64_t)(c) * cap * TILE_R;                                                     \
+        const int nrec_b_ = ntile_bound * TILE_R;                                                                     \
+        _Pragma("unroll") for (int q = 0; q < VQ; ++q) {                                                              \
+            const int j = q * 64 + lane;                                                                              \
+            key[q] = a.tkey[s_c_ + (j < nrec_b_ ? j : nrec_b_ - 1)];                                                  \
+        }                                                                                                             \
+        _Pragma("unroll") for (int rq = 0; rq < VQ / 4; ++rq) {                                                       \
+            const int x = rq * 64 + lane;                                                                             \
+            rho[rq] = a.trho[slot0 / TILE_R + (int64_t)(c) * cap + (x < ntile_bound ? x : ntile_bound - 1)];          \
+        }                                                                                                             \
+    }
+    if (wave < C) MOC_TILE_KEYS(wave)
+    // ... then what this thread steps (independent of the pooling; it queues behind the keys).  The small tensors' owners
+    // sit in different waves: their sums over the pairs run side by side, not one after the other in one wave
+    const int d = cb * 256 + t;                                                      // this thread's column of W1[h]
+    float pw = 0.f, pm = 0.f, pv = 0.f;
+    float pT = 0.f, pTm = 0.f, pTv = 0.f;                                            // this thread's element of W2 / b1 / b2
+    int tail = -1;                                                                   // flat index past W1: b1 | W2 | b2
+    if (cb == 0) {
+        if (t < 4) tail = H + t * H + h;                                             // W2[i = t][h]: wave 0
+        else if (t == 64) tail = h;                                                  // b1[h]: wave 1
+        else if (wg0 && t >= 128 && t < 132) tail = H + 4 * H + (t - 128);           // b2[i]: wave 2
+    }
+    float w2v = 0.f;
+    if (t < 4) w2v = a.W2[t * H + h];
+    if (a.apply_adam) {
+        const int e = h * D + d;
+        pw = a.W1[e]; pm = a.m_W1[e]; pv = a.v_W1[e];
+        if (tail >= H + 4 * H) { const int i = tail - 5 * H; pT = a.b2[i]; pTm = a.m_b2[i]; pTv = a.v_b2[i]; }
+        else if (tail >= H) { const int i = tail - H; pTm = a.m_W2[i]; pTv = a.v_W2[i]; }
+        else if (tail >= 0) { pT = a.b1[tail]; pTm = a.m_b1[tail]; pTv = a.v_b1[tail]; }
+    }
+    MOC_STAMP(19);
+    AdamCoef ak = a.adam;
+    if (a.adam_tab) ak = a.adam_tab[a.adam_ctr[0] + a.adam_pos];
+    const int S = a.n_sel[b];
+    const int y = (int)a.labels[b];
+    const int k = K < S ? K : S;
+    // LDS carve: the 16-byte things first
+    float4* plam = reinterpret_cast<float4*>(smem);                                  // [P] pairs' gates
+    float4* psc = plam + (size_t)C * K;                                              // [P] ... candidate scores
+    float* xs = reinterpret_cast<float*>(psc + (size_t)C * K);                       // [P][256] pairs' row pieces
+    float* dhs = xs + (size_t)C * K * 256;                                           // [P (+3)] dh of unit h, 16-byte aligned
+    float* dz = dhs + (((size_t)C * K + 3) & ~(size_t)3);                            // [P][4]
+    unsigned long long* list = reinterpret_cast<unsigned long long*>(dz + (size_t)C * K * 4);   // [C][PS_CAP]
+    unsigned long long* t0s = list + (size_t)C * PS_CAP;                             // [C] the bound T0 (as a key)
+    int64_t* prid = reinterpret_cast<int64_t*>(t0s + C);                             // [P]
+    int* lsrc = reinterpret_cast<int*>(prid + (size_t)C * K);                        // [C][CL] record of a candidate
+    float* topv = reinterpret_cast<float*>(lsrc + (size_t)C * CL);                   // [C][16]
+    float* pooled_s = topv + (size_t)C * 16;                                         // [C]
+    float* dpool = pooled_s + C;                                                     // [C]
+    int* ncand = reinterpret_cast<int*>(dpool + C);                                  // [C]
+    int* flagc = ncand + C;                                                          // [C] 1: the records cannot prove exactness
+    int* topk_s = flagc + C;                                                         // [C][K]
+    float* h1s = reinterpret_cast<float*>(topk_s + C * K);                           // [P]
+    float* w2s = h1s + (size_t)C * K;                                                // [4]
+    if (t < 4) { w2s[t] = w2v; if (tail >= H) pT = w2v; }
+    const int ntile = (S + 15) >> 4;
+    for (int c = wave; c < C; c += 4) {                                              // ---- class c: this wave's, start to end
+        const int64_t s_c = slot0 + (int64_t)c * cap * TILE_R;                       // the class's first record
+        if (c != wave) MOC_TILE_KEYS(c)
+        if (lane == 0) ncand[c] = 0;
+        // the score halves of the keys decide bound and candidates (32-bit maxima and compares); absent records: 0
+        uint32_t hi[VQ];
+        uint32_t m = 0u;
+        const int nrec = ntile * TILE_R;
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) {
+            hi[q] = q * 64 + lane < nrec ? (uint32_t)(key[q] >> 32) : 0u;
+            m = hi[q] > m ? hi[q] : m;
+        }
+        MOC_STAMP(20);
+        // group g = the tiles g, g + 16, ...: record j sits on lane j & 63, its tile is j >> 2 -- the four lanes 4g .. 4g + 3
+        // hold group g, whatever q.  Quad maxima, then every row gathers the sixteen of them.
+        {
+            const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+            m = o1 > m ? o1 : m;
+            const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+            m = o2 > m ? o2 : m;
+        }
+        const uint32_t gm = (uint32_t)__shfl((int)m, (lane & 15) * 4, 64);
+        int grank = 0;
+#define MOC_ROR(n) grank += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gm, 0x120 + n, 0xf, 0xf, false) > gm ? 1 : 0;
+        MOC_ROR(1) MOC_ROR(2) MOC_ROR(3) MOC_ROR(4) MOC_ROR(5) MOC_ROR(6) MOC_ROR(7) MOC_ROR(8)
+        MOC_ROR(9) MOC_ROR(10) MOC_ROR(11) MOC_ROR(12) MOC_ROR(13) MOC_ROR(14) MOC_ROR(15)
+#undef MOC_ROR
+        // T0 = the K-th largest group maximum: K scores are >= it.  (0: fewer than K groups hold a record, or two group
+        // maxima tie across the K-th place -- then every record is a candidate.)
+        const unsigned long long hit = __ballot(lane < 16 && grank == k - 1 && gm != 0u);
+        uint32_t T0 = 0u;
+        if (hit != 0ull) T0 = (uint32_t)__builtin_amdgcn_readlane((int)gm, __ffsll((long long)hit) - 1);
+        // the records >= T0: a lane with any takes its places in the list by ONE LDS add (few lanes have any)
+        // (an absent record's key half is 0: with the bound raised to 1 one compare tells both; the sixty-fours of records
+        // past the slide's last tile are skipped by uniform branches)
+        const uint32_t T1 = T0 > 1u ? T0 : 1u;
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < VQ; ++q)
+            if (q * 64 < nrec) cnt += hi[q] >= T1 ? 1 : 0;
+        if (cnt > 0) {
+            int pos = atomicAdd(&ncand[c], cnt);
+#pragma unroll
+            for (int q = 0; q < VQ; ++q) {
+                if (q * 64 < nrec && hi[q] >= T1) {
+                    if (pos < CL) {
+                        list[(size_t)c * PS_CAP + pos] = key[q];
+                        lsrc[c * CL + pos] = q * 64 + lane;
+                    }
+                    ++pos;
+                }
+            }
+        }
+        // ... and the proof that no score >= T0 is missing from the records: no tile's (TILE_R + 1)-th largest reaches T0
+        bool bad = false;
+#pragma unroll
+        for (int rq = 0; rq < VQ / 4; ++rq)
+            bad = bad || (rq * 64 + lane < ntile && rho[rq] != 0u && rho[rq] >= T0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int n = ncand[c];
+        const bool fall = __ballot(bad) != 0ull || n > CL || n < k || k <= 0;
+        if (lane == 0) { flagc[c] = fall ? 1 : 0; t0s[c] = (unsigned long long)T0 << 32; }
+        MOC_STAMP(11);
+        if (!fall) {                                                                 // (uniform over the wave)
+            const unsigned long long mine = lane < n ? list[(size_t)c * PS_CAP + lane] : 0ull;
+            const int jrec = lane < n ? lsrc[c * CL + lane] : 0;
+            // the candidate's operands: one round trip, under the ranking loop
+            const int64_t rid = a.trid[s_c + jrec];
+            const float4 lam = a.tlam[s_c + jrec];
+            const float4 scv = a.tsc[s_c + jrec];
+            int rank = 0;
+            for (int l = 0; l < n; ++l) rank += list[(size_t)c * PS_CAP + l] > mine ? 1 : 0;
+            MOC_STAMP(12);
+            if (lane < n && rank < k) {
+                topk_s[c * K + rank] = (int)(~(unsigned)mine);
+                topv[c * 16 + rank] = key_to_float((unsigned)(mine >> 32));
+                const int p = c * k + rank;
+                prid[p] = rid; plam[p] = lam; psc[p] = scv;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {                                                         // summed largest first
+                float sum = 0.f;
+                for (int r = 0; r < k; ++r) sum += topv[c * 16 + r];
+                pooled_s[c] = sum / (float)k;
+                if (wg0) {
+                    a.pooled_out[(int64_t)b * C + c] = pooled_s[c];
+                    if (a.topk_cnt_out) a.topk_cnt_out[(int64_t)b * C + c] = k;
+                }
+            }
+            if (a.topk_idx_out && wg0)
+                for (int r = lane; r < K; r += 64)
+                    a.topk_idx_out[((int64_t)b * C + c) * K + r] = r < k ? topk_s[c * K + r] : -1;
+        }
+    }
+    __syncthreads();
+    MOC_STAMP(13);
+    bool fast = true;
+    for (int c = 0; c < C; ++c) fast = fast && flagc[c] == 0;
+    if (wg0 && t == 0 && a.n_pair) *a.n_pair = fast ? MOC_TILE_PATH_RECORDS : MOC_TILE_PATH_FULL;   // (which path ran: tests, diagnostics)
+    if (!fast) {
+        // ---- fall-back: the same bound T0 (a valid one: K group maxima are K scores >= T0) over ALL mixed scores of the
+        // slide.  Compact code, not fast code: it runs when a tile holds more than TILE_R of the candidates.
+        if (t < C) ncand[t] = 0;
+        __syncthreads();
+        for (int c = 0; c < C; ++c) {
+            const unsigned long long T0 = t0s[c];
+            const float* col = a.mixed_in + (int64_t)c * a.stride + base;
+            for (int i = t; i < S; i += 256) {
+                const unsigned long long kk = ((unsigned long long)moc_key_desc(col[i]) << 32) | (unsigned)(~(unsigned)i);
+                if (kk >= T0) {
+                    const int pos = atomicAdd(&ncand[c], 1);
+                    if (pos < PS_CAP) list[(size_t)c * PS_CAP + pos] = kk;
+                }
+            }
+        }
+        __syncthreads();
+        for (int c = wave; c < C; c += 4) {                                          // k rounds of wave maximum
+            const int n = ncand[c];
+            const bool overflow = n > PS_CAP;                                        // pathological ties: straight from global
+            const float* col = a.mixed_in + (int64_t)c * a.stride + base;
+            unsigned long long prev = ~0ull;
+            float sum = 0.f;
+            for (int r = 0; r < k; ++r) {
+                unsigned long long best = 0ull;
+                if (!overflow) {
+                    for (int i = lane; i < n; i += 64) {
+                        const unsigned long long v = list[(size_t)c * PS_CAP + i];
+                        if (v < prev && v > best) best = v;
+                    }
+                } else {
+                    for (int i = lane; i < S; i += 64) {
+                        const unsigned long long v = ps_key(col, i, S);
+                        if (v < prev && v > best) best = v;
+                    }
+                }
+                best = wave_max_u64(best);
+                prev = best;
+                sum += key_to_float((unsigned)(best >> 32));
+                if (lane == 0) topk_s[c * K + r] = (int)(~(unsigned)best);
+            }
+            if (lane == 0) pooled_s[c] = k > 0 ? sum / (float)k : __uint_as_float(0x7FC00000u);   // mean over no rows = NaN, like torch
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0 && wg0) {
+                a.pooled_out[(int64_t)b * C + c] = pooled_s[c];
+                if (a.topk_cnt_out) a.topk_cnt_out[(int64_t)b * C + c] = k;
+            }
+            if (a.topk_idx_out && wg0)
+                for (int r = lane; r < K; r += 64)
+                    a.topk_idx_out[((int64_t)b * C + c) * K + r] = r < k ? topk_s[c * K + r] : -1;
+        }
+        __syncthreads();
+        const int P0 = C * k;
+        for (int p = t; p < P0; p += 256) {                                          // the pooled rows' operands, gathered
+            const unsigned kinv0 = (65536u + (unsigned)k - 1u) / (unsigned)k;
+            const int c = (int)(((unsigned)p * kinv0) >> 16);
+            const int sidx = topk_s[c * K + (p - c * k)];
+            prid[p] = a.sel_row[base + sidx];
+            plam[p] = reinterpret_cast<const float4*>(a.gates)[base + sidx];
+            float4 s4;
+            s4.x = a.cand[(int64_t)c * a.stride + base + sidx];
+            s4.y = a.cand[(int64_t)(C + c) * a.stride + base + sidx];
+            s4.z = a.cand[(int64_t)(2 * C) * a.stride + base + sidx];
+            s4.w = a.cand[(int64_t)(2 * C + 1) * a.stride + base + sidx];
+            psc[p] = s4;
+        }
+        __syncthreads();
+    }
+    MOC_STAMP(14);
+    MOC_STAMP(15);
+    // ---- round trip 2: the pairs' row pieces and their hidden activation of unit h
+    const int P = C * k;
+    if (P > 0) {                                                                     // (uniform)
+        const unsigned kinv = (65536u + (unsigned)k - 1u) / (unsigned)k;
+        if (wave == 3) {                                                             // the pairs' hidden activation of unit h
+            for (int p = lane; p < P; p += 64) {
+                const int c = (int)(((unsigned)p * kinv) >> 16);
+                h1s[p] = a.H1[(base + topk_s[c * K + (p - c * k)]) * H + h];
+            }
+        } else {                                                                     // row pieces -> fp32 in LDS: four in flight per wave
+            const int esz = a.xdt == MOC_F32 ? 4 : 2;
+            const int64_t col0 = (int64_t)cb * 256 * esz;
+            for (int p0 = wave; p0 < P; p0 += 12) {
+                const int p1 = p0 + 3, p2 = p0 + 6, p3 = p0 + 9;
+                const unsigned char* r0 = a.X + prid[p0] * (int64_t)D * esz + col0;
+                const unsigned char* r1 = a.X + prid[p1 < P ? p1 : p0] * (int64_t)D * esz + col0;
+                const unsigned char* r2 = a.X + prid[p2 < P ? p2 : p0] * (int64_t)D * esz + col0;
+                const unsigned char* r3 = a.X + prid[p3 < P ? p3 : p0] * (int64_t)D * esz + col0;
+                float4 v0, v1, v2, v3;
+                if (a.xdt == MOC_F32) {
+                    v0 = reinterpret_cast<const float4*>(r0)[lane]; v1 = reinterpret_cast<const float4*>(r1)[lane];
+                    v2 = reinterpret_cast<const float4*>(r2)[lane]; v3 = reinterpret_cast<const float4*>(r3)[lane];
+                } else {
+                    const bool f16 = a.xdt == MOC_F16;
+                    auto widen = [&](uint2 raw) {
+                        float4 o;
+                        if (f16) {
+                            o.x = moc_f16_to_f32((uint16_t)raw.x); o.y = moc_f16_to_f32((uint16_t)(raw.x >> 16));
+                            o.z = moc_f16_to_f32((uint16_t)raw.y); o.w = moc_f16_to_f32((uint16_t)(raw.y >> 16));
+                        } else {
+                            o.x = __uint_as_float(raw.x << 16); o.y = __uint_as_float(raw.x & 0xFFFF0000u);
+                            o.z = __uint_as_float(raw.y << 16); o.w = __uint_as_float(raw.y & 0xFFFF0000u);
+                        }
+                        return o;
+                    };
+                    const uint2 u0 = reinterpret_cast<const uint2*>(r0)[lane], u1 = reinterpret_cast<const uint2*>(r1)[lane];
+                    const uint2 u2 = reinterpret_cast<const uint2*>(r2)[lane], u3 = reinterpret_cast<const uint2*>(r3)[lane];
+                    v0 = widen(u0); v1 = widen(u1); v2 = widen(u2); v3 = widen(u3);
+                }
+                reinterpret_cast<float4*>(xs + (size_t)p0 * 256)[lane] = v0;
+                if (p1 < P) reinterpret_cast<float4*>(xs + (size_t)p1 * 256)[lane] = v1;
+                if (p2 < P) reinterpret_cast<float4*>(xs + (size_t)p2 * 256)[lane] = v2;
+                if (p3 < P) reinterpret_cast<float4*>(xs + (size_t)p3 * 256)[lane] = v3;
+            }
+        }
+    }
+    // cross entropy of the pooled logits, argmax and d loss / d pooled: the fourth wave, beside the others' row requests
+    if (wave == 3) {
+        const float xv = lane < C ? pooled_s[lane] : -INFINITY;
+        float mx = xv;
+        int arg = lane < C ? lane : 0x7fffffff;
+        for (int off = 8; off > 0; off >>= 1) {
+            const float om = __shfl_xor(mx, off, 64);
+            const int oa = __shfl_xor(arg, off, 64);
+            if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
+        }
+        const float ex = lane < C ? expf(xv - mx) : 0.f;
+        float se = ex;
+        for (int off = 8; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
+        const float lse = mx + logf(se);
+        if (lane < C) dpool[lane] = expf(xv - lse) - (lane == y ? 1.f : 0.f);
+        if (lane == 0 && wg0) {
+            a.loss[b] = lse - pooled_s[y];
+            a.pred[b] = arg;
+        }
+    }
+    __syncthreads();
+    MOC_STAMP(16);
+    for (int p = t; p < P; p += 256) {                   // thread = pair: its dz, and dh of hidden unit h
+        const unsigned kinv = (65536u + (unsigned)k - 1u) / (unsigned)k;
+        const int c = (int)(((unsigned)p * kinv) >> 16);
+        const float gk = dpool[c] / (float)k;
+        const float4 l4 = plam[p], s4 = psc[p];
+        const float lamv[4] = {l4.x, l4.y, l4.z, l4.w}, scs[4] = {s4.x, s4.y, s4.z, s4.w};
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dlam = (a.use_bits >> i & 1u) ? gk * scs[i] : 0.f;
+            const float dzi = dlam * lamv[i] * (1.f - lamv[i]);
+            dz[p * 4 + i] = dzi;
+            v = fmaf(dzi, w2s[i], v);
+        }
+        dhs[p] = h1s[p] > 0.f ? v : 0.f;
+    }
+    __syncthreads();
+    MOC_STAMP(17);
+    // ---- gradients of the owned elements, every sum over the pairs in ascending order (operands four pairs at a time:
+    // the additions stay in order, the LDS reads do not wait for each other)
+    float gr = 0.f;
+    {
+        int p = 0;
+        for (; p + 4 <= P; p += 4) {
+            const float4 d4 = *reinterpret_cast<const float4*>(dhs + p);
+            const float x0 = xs[(size_t)p * 256 + t], x1 = xs[(size_t)(p + 1) * 256 + t];
+            const float x2 = xs[(size_t)(p + 2) * 256 + t], x3 = xs[(size_t)(p + 3) * 256 + t];
+            gr = fmaf(d4.x, x0, gr); gr = fmaf(d4.y, x1, gr); gr = fmaf(d4.z, x2, gr); gr = fmaf(d4.w, x3, gr);
+        }
+        for (; p < P; ++p) gr = fmaf(dhs[p], xs[(size_t)p * 256 + t], gr);
+    }
+    float gt = 0.f;
+    if (tail >= H + 4 * H) {
+        const int i = tail - 5 * H;
+        int p = 0;
+        for (; p + 4 <= P; p += 4) {
+            const float z0 = dz[p * 4 + i], z1 = dz[(p + 1) * 4 + i], z2 = dz[(p + 2) * 4 + i], z3 = dz[(p + 3) * 4 + i];
+            gt += z0; gt += z1; gt += z2; gt += z3;
+        }
+        for (; p < P; ++p) gt += dz[p * 4 + i];
+    } else if (tail >= H) {
+        int p = 0;
+        for (; p + 4 <= P; p += 4) {
+            const float z0 = dz[p * 4 + t], z1 = dz[(p + 1) * 4 + t], z2 = dz[(p + 2) * 4 + t], z3 = dz[(p + 3) * 4 + t];
+            const float4 h4 = {h1s[p], h1s[p + 1], h1s[p + 2], h1s[p + 3]};
+            gt = fmaf(z0, h4.x, gt); gt = fmaf(z1, h4.y, gt); gt = fmaf(z2, h4.z, gt); gt = fmaf(z3, h4.w, gt);
+        }
+        for (; p < P; ++p) gt = fmaf(dz[p * 4 + t], h1s[p], gt);
+    } else if (tail >= 0) {
+        int p = 0;
+        for (; p + 4 <= P; p += 4) {
+            const float4 d4 = *reinterpret_cast<const float4*>(dhs + p);
+            gt += d4.x; gt += d4.y; gt += d4.z; gt += d4.w;
+        }
+        for (; p < P; ++p) gt += dhs[p];
+    }
+    if (!a.apply_adam) {                                  // gradient out (data-parallel step with a collective)
+        a.g_W1[h * D + d] = gr;
+        if (tail >= H + 4 * H) a.g_b2[tail - 5 * H] = gt;
+        else if (tail >= H) a.g_W2[tail - H] = gt;
+        else if (tail >= 0) a.g_b1[tail] = gt;
+        return;
+    }
+    const float gs = ak.grad_scale;
+    {
+        const int e = h * D + d;
+        adam_update(pw, pm, pv, gr * gs, ak);
+        a.W1[e] = pw; a.m_W1[e] = pm; a.v_W1[e] = pv;
+        w1_image_store(a.img_dt, a.W1img, D, h, d, pw);
+    }
+    if (tail >= 0) {
+        adam_update(pT, pTm, pTv, gt * gs, ak);
+        if (tail >= H + 4 * H) { const int i = tail - 5 * H; a.b2[i] = pT; a.m_b2[i] = pTm; a.v_b2[i] = pTv; }
+        else if (tail >= H) { const int i = tail - H; a.W2out[i] = pT; a.m_W2[i] = pTm; a.v_W2[i] = pTv; }
+        else { a.b1[tail] = pT; a.m_b1[tail] = pTm; a.v_b1[tail] = pTv; }
+    }
+    MOC_STAMP(18);
+    MOC_STAMP_MAX(35);
+}
+#undef MOC_TILE_KEYS
+
 // ------------------------------------------------------------------ one-launch step, wide shapes
 // C <= 64, K <= 16, S <= 8192 (EBRAINS-30, the 64-way stress shape): hundreds of gradient pairs, whose bag
 // rows (P x D) and hidden activations (P x 64) do not fit in LDS.  Same grid as pool_w1_step_kernel (16
@@ -2187,9 +2753,14 @@ int s_bound(const moc_batch_t* B) {
     return (int)(by_sel < B->max_rows ? by_sel : B->max_rows);
 }
 
+bool tiles_ok(const moc_batch_t* B, const moc_meta_ws_t* ws);
+
+// emit_tiles: the one-launch step over tile records follows (training step of one slide): leave the records
 int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, int slide0, int n,
-                   uint32_t use_bits, hipStream_t s) {
+                   uint32_t use_bits, hipStream_t s, bool emit_tiles = false) {
     FwdArgs a;
+    a.tile_on = 0; a.tile_cap = 0; a.tile_slot0 = 0;
+    a.tile = TileWs();
     a.X = (const unsigned char*)B->X; a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel;
     a.cand = B->cand; a.W1 = M->W1; a.b1 = M->b1; a.W2 = M->W2; a.b2 = M->b2;
     a.W1img = (const unsigned char*)M->W1_image;
@@ -2200,6 +2771,12 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
 #endif
     a.base_host = (n == 1 && B->row_off_host) ? B->row_off_host[slide0] : -1;
     a.cand_mode = 0; a.stats = nullptr; a.sel_idx = nullptr;
+    if (emit_tiles && n == 1 && a.base_host >= 0 && tiles_ok(B, ws)) {
+        a.tile_on = 1;
+        a.tile = tile_carve(ws->tile_ws, tile_slots(B->total_rows, B->n_slides, B->C));
+        a.tile_cap = moc_cdiv(B->row_off_host[slide0 + 1] - a.base_host, 16);
+        a.tile_slot0 = ((a.base_host >> 4) + slide0) * (int64_t)B->C * TILE_R;
+    }
     if (B->flags & MOC_CAND_FROM_STATS) {
         MOC_REQUIRE(B->stats && B->sel_idx, "moc_meta_forward: MOC_CAND_FROM_STATS needs the batch's stats and sel_idx");
         a.cand_mode = (B->flags & MOC_STATS_COMPACT) ? 2 : 1;
@@ -2349,6 +2926,21 @@ bool fused_step_ok(const moc_batch_t* B, const moc_meta_ws_t* ws) {
     return fused_step_smem(B, cap) <= FS_MAX_DYN_LDS;
 }
 
+// the one-launch step over the forward's tile records (pool_w1_step_tiles_kernel): the shapes of pool_w1_step_kernel, when
+// the caller has given the record arrays
+size_t tiles_step_smem(const moc_batch_t* B, int cap) {
+    const size_t C = B->C, K = B->topk, P = C * K, CL = 64;
+    return P * 32 + P * 256 * 4 + (P + 4) * 4 + P * 16 + C * cap * 8 + C * 8 + P * 8 + C * CL * 4 + C * 16 * 4 + C * 4 * 4 + P * 4 + P * 4 + 16 + 64;
+}
+bool tiles_ok(const moc_batch_t* B, const moc_meta_ws_t* ws) {
+    static const bool off = getenv("MOC_TILE_RECORDS") && atoi(getenv("MOC_TILE_RECORDS")) == 0;   // diagnostic: the round-3 step
+    if (off || !ws->tile_ws || !B->row_off_host || !fused_step_ok(B, ws)) return false;
+    if (moc_cdiv(s_bound(B), 16) * TILE_R > 16 * 64) return false;       // a class's records: at most sixteen keys per lane
+    if (ws->tile_ws_bytes < (int64_t)tile_bytes(tile_slots(B->total_rows, B->n_slides, B->C))) return false;
+    const int cap = B->C <= 8 ? PS_CAP_MAX : PS_CAP_MAX / 2;
+    return tiles_step_smem(B, cap) <= (size_t)FS_MAX_DYN_LDS;
+}
+
 // the wide one-launch step (pool_w1_step_wide_kernel): C <= 64, K <= 16, S <= 8192, every pair's D/16-column
 // piece in LDS
 int wide_cap(const moc_batch_t* B) {
@@ -2392,6 +2984,10 @@ void fused_step_attrs() {
     if (done) return;
     (void)hipFuncSetAttribute((const void*)pool_w1_step_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
     (void)hipFuncSetAttribute((const void*)pool_w1_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
+    (void)hipFuncSetAttribute((const void*)pool_w1_step_tiles_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
+    (void)hipFuncSetAttribute((const void*)pool_w1_step_tiles_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
+    (void)hipFuncSetAttribute((const void*)pool_w1_step_tiles_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
+    (void)hipFuncSetAttribute((const void*)pool_w1_step_tiles_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
     done = true;
 }
 
@@ -2440,6 +3036,43 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
         return MOC_OK;
     }
     const int cap = B->C <= 8 ? PS_CAP_MAX : PS_CAP_MAX / 2;
+    if (g.x.world <= 1 && tiles_ok(B, ws)) {               // over the forward's tile records (the forward was told to leave them)
+        fused_step_attrs();
+        const TileWs T = tile_carve(ws->tile_ws, tile_slots(B->total_rows, B->n_slides, B->C));
+        // the slide's region: cap tiles per class; the kernel's loads are issued before n_sel is known and clamped to the
+        // tiles the slide can have at all (at most s_bound selected rows)
+        const int tcap = moc_cdiv(a.seg_host, 16) > 0 ? moc_cdiv(a.seg_host, 16) : 1;
+        const int tb_all = moc_cdiv(s_bound(B), 16);
+        const int tb = tcap < tb_all ? tcap : tb_all;
+        TileStepArgs ta = {};
+        ta.tkey = T.key; ta.trho = T.rho; ta.trid = T.rid; ta.tlam = T.lam; ta.tsc = T.sc;
+        ta.slot0 = ((a.base_host >> 4) + slide) * (int64_t)B->C * TILE_R;
+        ta.cap = tcap; ta.ntile_bound = tb; ta.C = B->C; ta.K = B->topk; ta.D = B->D; ta.slide0 = slide; ta.PS_CAP = cap;
+        ta.xdt = B->dtype; ta.n_sel = B->n_sel; ta.labels = labels;
+        ta.W1 = M->W1; ta.m_W1 = M->m_W1; ta.v_W1 = M->v_W1; ta.W2 = M->W2;
+        ta.b1 = M->b1; ta.m_b1 = M->m_b1; ta.v_b1 = M->v_b1; ta.b2 = M->b2; ta.m_b2 = M->m_b2; ta.v_b2 = M->v_b2;
+        ta.m_W2 = M->m_W2; ta.v_W2 = M->v_W2;
+        ta.base = a.base_host; ta.adam = k;
+        if (tab) { ta.adam_tab = tab->tab; ta.adam_ctr = tab->ctr; ta.adam_pos = tab->pos; }
+        ta.apply_adam = apply_adam; ta.use_bits = use_bits; ta.img_dt = B->dtype;
+        ta.H1 = ws->H1; ta.X = (const unsigned char*)B->X;
+        ta.pooled_out = ws->pooled; ta.topk_idx_out = ws->topk_idx; ta.topk_cnt_out = ws->topk_cnt;
+        ta.loss = ws->loss; ta.pred = ws->pred; ta.n_pair = ws->n_pair;
+        ta.W1img = (unsigned char*)M->W1_image; ta.W2out = W2out;
+        ta.g_W1 = M->g_W1; ta.g_b1 = M->g_b1; ta.g_W2 = M->g_W2; ta.g_b2 = M->g_b2;
+        ta.mixed_in = ws->mixed; ta.cand = B->cand; ta.gates = ws->gates; ta.sel_row = B->sel_row; ta.stride = B->total_rows;
+        const size_t sm = tiles_step_smem(B, cap);
+        const dim3 grid(B->D / 256, H);
+#define MOC_TILES_LAUNCH(VQ) pool_w1_step_tiles_kernel<VQ><<<grid, 256, sm, s>>>(ta)
+        const int vq = moc_cdiv((int64_t)tb * TILE_R, 64);                 // keys per lane of a class wave
+        if (vq <= 4) MOC_TILES_LAUNCH(4);
+        else if (vq <= 8) MOC_TILES_LAUNCH(8);
+        else if (vq <= 12) MOC_TILES_LAUNCH(12);
+        else MOC_TILES_LAUNCH(16);
+#undef MOC_TILES_LAUNCH
+        MOC_CHECK_LAUNCH("moc_fused_step(tiles)");
+        return MOC_OK;
+    }
     const size_t smem = fused_step_smem(B, cap);
     static bool attr_set = false;
     if (!attr_set) {
@@ -2532,7 +3165,7 @@ extern "C" int moc_train_grad(const moc_batch_t* B, const moc_meta_t* M, const m
     // forward (fresh W1 image: the parameters may have been stepped by moc_adam_step), pooling +
     // loss + pair gradients, W1 gradient -- everything one meta-step does short of the update
     if (int rc = launch_w1_image(B, M, s)) return rc;
-    if (int rc = launch_forward(B, M, ws, slide, 1, use_bits, s)) return rc;
+    if (int rc = launch_forward(B, M, ws, slide, 1, use_bits, s, true)) return rc;
     if (fused_step_mode(B, ws)) return launch_fused_step(B, M, ws, labels, slide, use_bits, k, nullptr, s, 0);
     if (int rc = launch_pool_finish(B, M, ws, labels, slide, 1, 1, 0, use_bits, k, s)) return rc;
     return launch_w1(B, M, ws, 0, k, s, fused_ok(B, 1));
@@ -2592,7 +3225,7 @@ extern "C" int moc_train_steps_dp(const moc_batch_t* B, const moc_meta_t* M, con
     kg.grad_scale = 1.f;
     for (int t = 0; t < n; ++t) {
         const int b = slide0 + t;
-        if (int rc = launch_forward(B, M, ws, b, 1, use_bits, s)) return rc;
+        if (int rc = launch_forward(B, M, ws, b, 1, use_bits, s, fused)) return rc;
         if (fused) {
             if (int rc = launch_fused_step(B, M, ws, labels, b, use_bits, kg, nullptr, s, 0)) return rc;
         } else {
@@ -2730,8 +3363,8 @@ __global__ void step_ctr_add_kernel(int32_t* ctr, int32_t n) { ctr[0] += n; }
 struct GraphKey {            // everything a captured pass bakes into its kernel arguments
     const void *X, *row_off, *sel_row, *n_sel, *cand, *labels;
     const void *W1, *b1, *W2, *b2, *mW1, *mb1, *mW2, *mb2, *vW1, *vb1, *vW2, *vb2, *img;
-    const void *H1, *gates, *mixed, *pooled, *topk_idx, *topk_cnt, *loss, *pred, *pair_dh, *W2_alt, *pair_row, *n_pair;
-    int64_t total_rows;
+    const void *H1, *gates, *mixed, *pooled, *topk_idx, *topk_cnt, *loss, *pred, *pair_dh, *W2_alt, *pair_row, *n_pair, *tile_ws;
+    int64_t total_rows, tile_ws_bytes;
     uint64_t off_hash;       // FNV-1a of row_off_host[slide0 .. slide0 + n]
     int32_t dtype, D, n_slides, C, Ce, topj, topk, s_bound, mode, external, slide0, n;
     uint32_t use_bits, flags;  // flags: MOC_FORWARD_ROWS64 / MOC_FORWARD_FOUR_WAVES pick the forward kernel a capture bakes in
@@ -2746,7 +3379,7 @@ void graph_key(GraphKey* k, const moc_batch_t* B, const moc_meta_t* M, const moc
     k->mb2 = M->m_b2; k->vW1 = M->v_W1; k->vb1 = M->v_b1; k->vW2 = M->v_W2; k->vb2 = M->v_b2; k->img = M->W1_image;
     k->H1 = ws->H1; k->gates = ws->gates; k->mixed = ws->mixed; k->pooled = ws->pooled; k->topk_idx = ws->topk_idx;
     k->topk_cnt = ws->topk_cnt; k->loss = ws->loss; k->pred = ws->pred; k->pair_dh = ws->pair_dh; k->W2_alt = ws->W2_alt;
-    k->pair_row = ws->pair_row; k->n_pair = ws->n_pair;
+    k->pair_row = ws->pair_row; k->n_pair = ws->n_pair; k->tile_ws = ws->tile_ws; k->tile_ws_bytes = ws->tile_ws_bytes;
     k->total_rows = B->total_rows;
     uint64_t h = 1469598103934665603ull;
     if (B->row_off_host)
@@ -2775,7 +3408,7 @@ int issue_fused_pass(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_w
         if (G) { st.tab = G->tab; st.ctr = G->ctr; st.pos = t; }
         else k = adam_coef(M, M->step + 1 + t, 1.f);
         Mt.W2 = cur;
-        if (int rc = launch_forward(B, &Mt, ws, b, 1, use_bits, s)) return rc;
+        if (int rc = launch_forward(B, &Mt, ws, b, 1, use_bits, s, true)) return rc;
         if (int rc = launch_fused_step(B, &Mt, ws, labels, b, use_bits, k, nxt, s, 1, nullptr, G ? &st : nullptr)) return rc;
         float* tmp = cur; cur = nxt; nxt = tmp;
     }
@@ -2958,6 +3591,11 @@ extern "C" int moc_train_steps_graph(moc_step_graph_t* G, const moc_batch_t* B, 
     G->has_last = hipEventRecord(G->last_done, s) == hipSuccess;
     G->last_stream = s;
     return MOC_OK;
+}
+
+extern "C" size_t moc_tile_ws_bytes(int64_t total_rows, int n_slides, int C) {
+    if (total_rows <= 0 || n_slides <= 0 || C <= 0) return 0;
+    return tile_bytes(tile_slots(total_rows, n_slides, C));
 }
 
 extern "C" size_t moc_w1_image_bytes(int D, int dtype) {

@@ -1219,6 +1219,9 @@ static void launch_stream_ticketed(const ScoresArgs& a, int wgs, size_t smem, hi
     }
 }
 
+#ifndef MOC_LOOKAHEAD_WGS_DEFAULT
+#define MOC_LOOKAHEAD_WGS_DEFAULT 0
+#endif
 static int scores_impl(const moc_batch_t* B, const void* bank, moc_stream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (int rc = moc_check_batch(B, "moc_scores")) return rc;
     MOC_REQUIRE(bank && B->stats && B->sel_flag, "moc_scores: null bank/stats/sel_flag");
@@ -1261,6 +1264,15 @@ static int scores_impl(const moc_batch_t* B, const void* bank, moc_stream_t stre
         int wgs = (int)((tiles + 3) / 4);
         const int resident = 256 * (smem <= 80 * 1024 ? 2 : 1);
         if (wgs > resident) wgs = resident;
+        // A look-ahead launch (tile_ticket set: it runs beside the meta-steps of the pass before) is kept to fewer
+        // persistent workgroups: every wave of this kernel holds up to 32 KiB of loads in flight, 2,048 waves 64 MB --
+        // several times what 8 TB/s x the memory latency can use, and every dependent load of a meta-step queues
+        // behind them (profiles/NOTES.md round 4: the steps crawl while a full-width score pass streams, whether or
+        // not it leaves them compute units).  MOC_LOOKAHEAD_WGS overrides (0: no cap).
+        if (B->tile_ticket) {
+            static const int cap_env = getenv("MOC_LOOKAHEAD_WGS") ? atoi(getenv("MOC_LOOKAHEAD_WGS")) : MOC_LOOKAHEAD_WGS_DEFAULT;
+            if (cap_env > 0 && wgs > cap_env) wgs = cap_env;
+        }
         const int row_b = B->D * moc_elem_size(B->dtype);
 #define MOC_LAUNCH_STREAM(NF, BF, NTT, FH)                                                              \
         do {                                                                                            \

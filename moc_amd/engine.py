@@ -32,6 +32,8 @@ COMPACT_STATS = os.environ.get("MOC_COMPACT_STATS", "1") != "0"     # wide banks
 # 64 -> 45.6 k, 96 -> 42.9 k meta-steps/s; the ticketed walk alone costs the score pass 7 % (fp32) / 19 % (bf16), so
 # passes with nothing beside them (evaluation) keep the static walk.
 RESERVE_CUS = int(os.environ.get("MOC_RESERVE_CUS", "64"))
+# the training step pools among the forward's tile records (moc_meta_ws_t.tile_ws; 0: re-reads every mixed score, round 3)
+TILE_RECORDS = os.environ.get("MOC_TILE_RECORDS", "1") != "0"
 
 # bench.py sets this to a list: every batched score-pass launch then appends
 # (start_event, stop_event, algorithmic_bytes) recorded on the launch stream.
@@ -101,9 +103,9 @@ def choose_reserved_slots(slots, n):
     dealt round-robin over its shader engines / arrays (HW_ID[15:12]), the highest CU id of each first.  Pure."""
     n = int(n)
     assert n > 0, f"{n} reserved compute units"
-    # a smaller part or partition (CPX / DPX, HSA_CU_MASK), or a census that saw less: never more than half of what
-    # exists; an empty result tells the caller to keep the static whole-chip walk
-    n = min(n, len(slots) // 2)
+    # a smaller part or partition (CPX / DPX, HSA_CU_MASK), or a census that saw less: never more than three quarters of
+    # what exists; an empty result tells the caller to keep the static whole-chip walk
+    n = min(n, len(slots) * 3 // 4)
     if n <= 0:
         return []
     xccs = sorted({x for x, _ in slots})
@@ -114,7 +116,7 @@ def choose_reserved_slots(slots, n):
         for _, s_ in (t for t in slots if t[0] == x):
             groups.setdefault(s_ >> 4, []).append(s_)                # HW_ID[15:12] = SE | SH; [11:8] = CU
         order = [sorted(g, reverse=True) for _, g in sorted(groups.items())]
-        want = min(want, sum(len(g) for g in order) // 2)          # (an incomplete census: never more than half of what was seen)
+        want = min(want, sum(len(g) for g in order) * 3 // 4)      # (an incomplete census: never more than three quarters of what was seen)
         k = 0
         while want > 0:
             g = order[k % len(order)]
@@ -356,7 +358,10 @@ class SlideBatch:
                 pair_dh=torch.empty((Cc * K, HIDDEN), **f32),
                 W2_alt=torch.empty((4, HIDDEN), **f32),
                 pair_row=torch.empty(Cc * K, dtype=torch.int64, device=dev), n_pair=torch.zeros(1, **i32))
-            self._ws = (t, MocMetaWs(**{k: ptr(v) for k, v in t.items()}))
+            # tile records (include/moc_hip.h moc_meta_ws_t.tile_ws): what the training forward leaves for the step kernel
+            nb = lib().moc_tile_ws_bytes(T, n, Cc) if TILE_RECORDS else 0
+            t["tile_ws"] = torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None
+            self._ws = (t, MocMetaWs(**{k: ptr(v) for k, v in t.items()}, tile_ws_bytes=nb))
         return self._ws
 
 

@@ -70,7 +70,7 @@ class _SenetFn(torch.autograd.Function):
         batch.n_sel.fill_(S)
         batch.set_layout([0, S])
         meta = MetaState(model)
-        keep = torch.is_grad_enabled() and any(p.requires_grad for p in (W1, b1, W2, b2))
+        keep = any(ctx.needs_input_grad[1:5])            # (grad mode is off inside forward(): ask the context)
         engine.meta_forward(batch, meta, 0, 1, 0, keep_hidden=True)
         t, _ = batch.meta_ws()
         if keep:

@@ -46,7 +46,7 @@ def test_struct_layout_matches_c_compiler(tmp_path):
         "int main(void){\n"
         ' printf("%zu %zu %zu %zu %zu\\n", sizeof(moc_batch_t), offsetof(moc_batch_t, row_off_host), offsetof(moc_batch_t, x_off), offsetof(moc_batch_t, C), offsetof(moc_batch_t, cand));\n'
         ' printf("%zu %zu %zu %zu\\n", sizeof(moc_meta_t), offsetof(moc_meta_t, lr), offsetof(moc_meta_t, H), offsetof(moc_meta_t, step));\n'
-        ' printf("%zu %zu\\n", sizeof(moc_meta_ws_t), offsetof(moc_meta_ws_t, n_pair));\n'
+        ' printf("%zu %zu\\n", sizeof(moc_meta_ws_t), offsetof(moc_meta_ws_t, tile_ws_bytes));\n'
         " return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
@@ -56,7 +56,7 @@ def test_struct_layout_matches_c_compiler(tmp_path):
     B, M, W = _lib.MocBatch, _lib.MocMeta, _lib.MocMetaWs
     exp = [ctypes.sizeof(B), B.row_off_host.offset, B.x_off.offset, B.C.offset, B.cand.offset,
            ctypes.sizeof(M), M.lr.offset, M.H.offset, M.step.offset,
-           ctypes.sizeof(W), W.n_pair.offset]
+           ctypes.sizeof(W), W.tile_ws_bytes.offset]
     assert got == exp
 
 

@@ -1079,3 +1079,84 @@ def test_wave_per_task_topk_gives_the_workgroup_kernels_bits(dev, K, smallest, s
     order = torch.argsort(-col if not smallest else col, stable=True)[:K]
     assert i_w[s_i, c_i].cpu().tolist() == order.tolist()
 
+
+
+# ------------------------------------------------------------------ round 4: the step over the forward's tile records
+def _train_epochs(dev, tile_records, C, D, dtype, sizes, j, K, epochs, seed, discard=(), plant=None):
+    """`epochs` passes of main_moc.train over a resident split with the tile-record step on or off; -> everything a
+    step leaves behind, as host arrays."""
+    M, E = _mm(), _engine()
+    keep = E.TILE_RECORDS
+    E.TILE_RECORDS = tile_records
+    try:
+        W, We = synth.make_bank(seed, D, C)
+        bags, labels = synth.make_slide_set(seed + 100, sizes, D, We, C)
+        if plant is not None:
+            bags = [plant(b_, We) for b_ in bags]
+        M.set_classifier_bank(W.to(dev), We.to(dev))
+        torch.manual_seed(seed)
+        model = M.senet(D, 4).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        res = M.ResidentBags([b_.to(dtype) for b_ in bags], labels, dev)
+        args = H.make_args(C, j, K, discard)
+        torch.manual_seed(seed + 7)
+        out = {"loss": [], "pooled": [], "topk": [], "path": []}
+        for _ in range(epochs):
+            M.train(model, res, opt, dev, args)
+            torch.cuda.synchronize()
+            t = M.train.last[0].meta_ws()[0]
+            out["loss"].append(t["loss"].cpu().numpy().copy())
+            out["pooled"].append(t["pooled"].cpu().numpy().copy())
+            out["topk"].append(t["topk_idx"].cpu().numpy().copy())
+            out["path"].append(int(t["n_pair"].cpu()[0]))
+        out["params"] = H.flat_params(model)
+        out["m"], out["v"] = H.flat_state(opt, "exp_avg"), H.flat_state(opt, "exp_avg_sq")
+        return out
+    finally:
+        E.TILE_RECORDS = keep
+
+
+@pytest.mark.parametrize("C,D,dtype,sizes,j,K,discard", [
+    (2, 512, torch.float32, [3000, 2500, 4100, 2800, 3333], 400, 10, ()),
+    (2, 512, torch.bfloat16, [3000, 2500, 4100], 400, 10, ("delta_diff",)),
+    (3, 512, torch.float32, [2000, 2600, 1500, 2200], 300, 10, ()),
+    (2, 256, torch.float16, [900, 700, 1100], 100, 1, ()),
+    (4, 768, torch.float32, [1500, 1200, 1700], 150, 5, ("topk",)),
+    (2, 512, torch.float32, [40, 18, 9, 300], 400, 10, ()),          # slides smaller than a few tiles, S < K
+    (2, 1024, torch.float32, [2500, 1800], 400, 10, ()),
+])
+def test_tile_record_step_gives_the_full_score_steps_bits(dev, C, D, dtype, sizes, j, K, discard):
+    """the step kernel pools among the records the forward leaves per 16-row tile instead of
+    re-reading and ranking every mixed score.  Same pooled rows in the same (value desc, row asc) order, the same sums:
+    losses, pooled logits, pooled rows, parameters and both Adam moments are BIT-identical to the round-3 step after
+    three passes, and the records path (not its fall-back) is what ran."""
+    a = _train_epochs(dev, False, C, D, dtype, sizes, j, K, 3, 4242 + C, discard)
+    b = _train_epochs(dev, True, C, D, dtype, sizes, j, K, 3, 4242 + C, discard)
+    for e in range(3):
+        np.testing.assert_array_equal(a["loss"][e], b["loss"][e])
+        np.testing.assert_array_equal(a["pooled"][e], b["pooled"][e])
+        np.testing.assert_array_equal(a["topk"][e], b["topk"][e])
+    for k in ("params", "m", "v"):
+        np.testing.assert_array_equal(a[k], b[k])
+    assert all(p not in (1000001, 1000002) for p in a["path"])      # round-3 kernel: no marker
+    assert b["path"][-1] in (1000001, 1000002)                      # the tile-record kernel ran the last step ...
+    if min(sizes) > 1000:
+        assert b["path"][-1] == 1000001                             # ... on its records
+
+
+def test_tile_record_step_falls_back_when_a_tile_holds_the_candidates(dev):
+    """Sixteen consecutive rows that all carry the class signal: one tile then holds more than four of the pooled rows,
+    the records cannot prove exactness (rho >= T0) and the kernel ranks the full scores instead -- same bits."""
+    def plant(bag, We):
+        bag = bag.clone()
+        bag[32:48] = torch.nn.functional.normalize(bag[32:48] * 0.2 + 3.0 * We[:, 0], dim=1)
+        return bag
+    sizes = [3000, 2500, 2800]
+    a = _train_epochs(dev, False, 2, 512, torch.float32, sizes, 400, 10, 2, 777, plant=plant)
+    b = _train_epochs(dev, True, 2, 512, torch.float32, sizes, 400, 10, 2, 777, plant=plant)
+    for e in range(2):
+        np.testing.assert_array_equal(a["loss"][e], b["loss"][e])
+        np.testing.assert_array_equal(a["topk"][e], b["topk"][e])
+    for k in ("params", "m", "v"):
+        np.testing.assert_array_equal(a[k], b[k])
+    assert b["path"][-1] == 1000002
