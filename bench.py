@@ -88,7 +88,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady_state block")
-    ap.add_argument("--steady-epochs", type=int, default=50)
+    ap.add_argument("--steady-epochs", type=int, default=3200,
+                    help="whole epochs of the same model timed right after the --steps region (default: 3,200 epochs = 102,400 "
+                         "meta-steps, about 2 s of GPU time: long enough for an outside sampler of GPU activity to see it)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--train-mode", default="seq", choices=["seq", "dp"],
                     help="N > 1: seq = exact-sequential (one Adam step per slide, bit-identical to one GPU; default); "

@@ -513,9 +513,10 @@ class MetaState:
         b1, b2 = g["betas"]
         c = self.c
         c.lr, c.beta1, c.beta2, c.eps, c.weight_decay = float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"])
-        steps = {int(float(self.optimizer.state[p]["step"])) for p in self.params}
-        assert len(steps) == 1, "parameters disagree on the Adam step count"
-        c.step = steps.pop()
+        st = self.optimizer.state
+        s0 = int(st[self.params[0]]["step"])
+        assert all(int(st[p]["step"]) == s0 for p in self.params[1:]), "parameters disagree on the Adam step count"
+        c.step = s0
 
     def step_graph(self):
         """The moc_step_graph_t of this meta-learner (created on first use).  None when switched off, and for a

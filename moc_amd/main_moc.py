@@ -183,13 +183,15 @@ class ResidentBags:
             self.starts.append(self.starts[-1] + n)
         self.dataset = self
         self._plans = {}
+        self._last_train_key = None
         self._order = None
 
     def train_plan(self, C_, Ce, topj, topk, discard):
         """Work arrays, labels and pinned mask staging for train() over the current visit order,
         built once and reused every epoch (only the mask bytes change)."""
-        order = tuple(self.visit_order())
-        key = (order, C_, Ce, topj, topk, tuple(sorted(discard or ())))
+        order = self.visit_order()                         # (a cached tuple)
+        key = (order, C_, Ce, topj, topk, tuple(sorted(discard)) if discard else ())
+        self._last_train_key = key
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) > 8:
@@ -362,7 +364,7 @@ def _issue_phase_a(plan, turn, bank, rng_before, host_wait=None, chain_plan=None
     return rng_after
 
 
-def _resident_pass_setup(res, device, args):
+def _resident_pass_setup(res, device, args, defer_rng=False):
     """Train pass over a resident split: nothing is copied or allocated per epoch except the new mask
     bytes.  Returns (batch with this epoch's phase A issued, device labels, bank).
 
@@ -379,8 +381,14 @@ def _resident_pass_setup(res, device, args):
     lab = plan["labels"]
     now = torch.get_rng_state()
     ahead, plan["ahead"] = plan["ahead"], None
+    plan["rng_after"] = None
     if ahead is not None and ahead["bank"] is bank and ahead["after"] is not None and torch.equal(ahead["before"], now):
-        torch.set_rng_state(ahead["after"])             # the draws happened: put the generator where they leave it
+        # the draws happened: the generator is put where they leave it -- by the caller, AFTER the pass's launches are
+        # issued (train(): 3 us that the first launch of the pass need not wait for)
+        if defer_rng:
+            plan["rng_after"] = ahead["after"]
+        else:
+            torch.set_rng_state(ahead["after"])
         ahead["done"].wait(engine.stream_obj())         # (the current stream waits; its Stream object is a cached one)
         plan["turn"] = ahead["turn"]
     else:
@@ -462,7 +470,7 @@ def train(model, train_loader, optimizer, device, args):
         if _TRACE:
             import time
             t0 = time.perf_counter()
-        batch, lab, bank = _resident_pass_setup(train_loader, device, args)      # phase A issued (or adopted)
+        batch, lab, bank = _resident_pass_setup(train_loader, device, args, defer_rng=True)      # phase A issued (or adopted)
         if _TRACE:
             t1 = time.perf_counter()
         meta = MetaState.cached(model, optimizer)
@@ -471,6 +479,10 @@ def train(model, train_loader, optimizer, device, args):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         engine.train_steps(batch, meta, lab, 0, batch.n_slides, use)
+        plan_ = train_loader._plans.get(train_loader._last_train_key)
+        if plan_ is not None and plan_.get("rng_after") is not None:
+            torch.set_rng_state(plan_["rng_after"])     # (see _resident_pass_setup)
+            plan_["rng_after"] = None
         if _TRACE:
             ev1.record()
             train.trace_events = getattr(train, "trace_events", [])[-200:] + [(batch.n_slides, ev0, ev1)]
