@@ -514,12 +514,21 @@ def main():
                 mdist.train_dp.last[0] if main_mode.startswith("dp") else M.train.last[0])
         Xl = res.local.X if main_mode == "seq" else res.X
         torch.cuda.synchronize()
-        iso = []
-        for _ in range(10):
-            e0, e1 = engine.timed_scores(last, M._bank_for(Xl, dev))
+
+        def alone_ms(batch):
+            """Median duration of the batch's score launch with nothing else on the GPU: launches back to back on the one
+            stream (each is alone: the stream serialises them), three of them untimed first and no host synchronisation
+            in between -- a launch after an idle gap runs on clocks that have dropped (round 3 timed every launch behind a
+            fence and reported `alone` SLOWER than the live launches on the wide configurations)."""
+            bank_ = M._bank_for(Xl, dev)
+            for _ in range(3):
+                engine.timed_scores(batch, bank_)
+            evs = [engine.timed_scores(batch, bank_) for _ in range(10)]
             torch.cuda.synchronize()
-            iso.append(e0.elapsed_time(e1))
-        iso_ms = sorted(iso)[len(iso) // 2]
+            t = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+            return t[len(t) // 2]
+
+        iso_ms = alone_ms(last)
         iso_bytes = last.kept_rows_host * D * esz
         roof["alone"] = {"achieved": round(iso_bytes / (iso_ms * 1e-3) / 1e9, 1),
                          "frac": round(iso_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launch_us": round(iso_ms * 1e3, 2),
@@ -528,14 +537,9 @@ def main():
             keep = (last.c.tile_ticket, last.c.cu_reserved)
             last.c.tile_ticket, last.c.cu_reserved = None, None
             try:
-                iso = []
-                for _ in range(10):
-                    e0, e1 = engine.timed_scores(last, M._bank_for(Xl, dev))
-                    torch.cuda.synchronize()
-                    iso.append(e0.elapsed_time(e1))
+                w_ms = alone_ms(last)
             finally:
                 last.c.tile_ticket, last.c.cu_reserved = keep
-            w_ms = sorted(iso)[len(iso) // 2]
             roof["whole_chip"] = {"kernel": kname.replace(", true>", ", false>"), "achieved": round(iso_bytes / (w_ms * 1e-3) / 1e9, 1),
                                   "frac": round(iso_bytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launch_us": round(w_ms * 1e3, 2)}
 
