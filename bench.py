@@ -110,6 +110,9 @@ def parse():
     ap.add_argument("--packed-runs", type=int, default=4,
                     help="N = 1: also measure this many independent training runs side by side on the ONE GPU (separate processes, "
                          "as scripts/moc_train.sh of the reference packs five folds onto a GPU); 0 = skip")
+    ap.add_argument("--batched-runs", default="8,16",
+                    help="N = 1: also time R independent runs batched in THIS process (moc_amd.runs), for every R of this "
+                         "comma-separated list (the `batched_runs` block; '' or 0: skip)")
     ap.add_argument("--replicas-only", action="store_true", help=argparse.SUPPRESS)      # the child of --packed-runs
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel trainer even at 1 GPU (rehearsal)")
     ap.add_argument("--force-seq", action="store_true", help="run the exact-sequential multi-GPU trainer even at 1 GPU "
@@ -651,6 +654,53 @@ def main():
                                "scripts/moc_train.sh packs five folds onto one GPU; moc_amd.run_many is its job queue.  One run is a "
                                "latency chain that leaves most of the GPU idle; independent runs interleave")
 
+    # ---- the same, inside ONE process: R independent runs stepped in lockstep by one launch pair per meta-step
+    # (moc_amd.runs / moc_train_steps_runs).  `value` above stays the rate of ONE run.
+    batched = None
+    if world == 1 and a.batched_runs not in ("", "0") and not a.replicas_only and not (a.force_dp or a.force_seq):
+        batched = {}
+        for R_ in [int(v) for v in a.batched_runs.split(",") if int(v) > 1]:
+            try:
+                torch.cuda.synchronize()
+                models_, opts_, splits_ = [], [], []
+                for r_ in range(R_):
+                    bags_ = [synth.make_bag_device(50000 + 1000 * r_ + i, a.patches, D, We, C, i % C, dev, store) for i in range(a.slides)]
+                    splits_.append(M.ResidentBags(bags_, [i % C for i in range(a.slides)], dev))
+                    del bags_
+                    torch.manual_seed(r_)
+                    m_ = M.senet(D, 4).to(dev)
+                    models_.append(m_)
+                    opts_.append(torch.optim.Adam(m_.parameters(), lr=1e-3, weight_decay=1e-4))
+                for _ in range(6):
+                    M.train_runs(models_, splits_, opts_, dev, args)
+                fence()
+                engine.SCORE_EVENTS = []
+                E_ = 40
+                t0 = time.perf_counter()
+                for _ in range(E_):
+                    M.train_runs(models_, splits_, opts_, dev, args)
+                fence()
+                bdt = time.perf_counter() - t0
+                ev_, engine.SCORE_EVENTS = engine.SCORE_EVENTS, None
+                sms = sum(s_.elapsed_time(e_) for s_, e_, _ in ev_)
+                sby = sum(b_ for _, _, b_ in ev_)
+                batched[f"runs_{R_}"] = {
+                    "runs": R_, "value": round(R_ * a.slides * E_ / bdt, 1), "unit": "meta-steps/s (all runs together, ONE GPU, ONE process)",
+                    "vs_one_run": round(R_ * a.slides * E_ / bdt / value, 2), "passes": E_, "us_per_pass": round(bdt / E_ * 1e6, 1),
+                    "score_pass": {"achieved": round(sby / (sms * 1e-3) / 1e9, 1), "frac": round(sby / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "unit": "GB/s", "avg_launch_us": round(sms / max(1, len(ev_)) * 1e3, 1),
+                                   "note": "one launch over the R x %d slides of a pass, whole chip, nothing beside it" % a.slides}}
+                del models_, opts_, splits_
+                M._run_sets.clear()
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001 -- an extra block must not cost the line its `value`
+                engine.SCORE_EVENTS = None
+                batched[f"runs_{R_}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        batched["note"] = ("R independent training runs (own slides, parameters, Adam state, mask stream) in ONE process: one forward "
+                           "and one step launch per meta-step serve all of them (grid.y / grid.z = run), phase A over all R x n "
+                           "slides in one pass.  Per run bit-identical to main_moc.train (tests/test_gpu_runs.py).  The reference's "
+                           "scripts/moc_train.sh:11-31 starts these runs as separate processes")
+
     # ---- CPU baseline: the oracle's train loop AND evaluation loop on the host cores (rank 0, N=1 only), a bounded
     # sample of the same workload (slide-granular: wide configurations do not get through an epoch in the budget)
     cpu = None
@@ -748,6 +798,8 @@ def main():
             out["replicas"] = replicas
         if packed:
             out["packed_runs"] = packed
+        if batched:
+            out["batched_runs"] = batched
         if extras:
             out["minibatch_dp" if main_mode == "seq" else "other_modes"] = dict(
                 extras, note="synchronous minibatch data parallelism: one Adam step per N slides -- an opt-in extension "

@@ -273,6 +273,22 @@ int moc_pool_loss(const moc_batch_t* B, const moc_meta_ws_t* ws, const int64_t* 
 int moc_ce_loss(const float* pooled, const int64_t* labels, int n, int C, float* loss, int32_t* pred,
                 moc_stream_t stream);
 
+/* Batched runs (round 4): `n_runs` independent meta-learners stepped in lockstep by ONE forward launch and ONE step launch
+ * per meta-step (grid.y / grid.z = run) -- the folds x shots of the reference's launcher (scripts/moc_train.sh:11-31) as
+ * one process per GPU instead of one process per run.  Run r owns the slides slide0 + r * slide_stride ... of B, its tensors
+ * lie par_stride floats behind run 0's in ONE arena per kind (W1 | b1 | W2 | b2 of a run inside one block, the moments
+ * laid out alike), its W1 operand image image_stride bytes behind run 0's.  All runs share the Adam hyper-parameters and
+ * step count of M.  Per run the arithmetic is moc_train_steps's: bit-identical parameters. */
+typedef struct moc_runs {
+    int32_t n_runs;        /* 1 .. 16 */
+    int32_t slide_stride;  /* slides of B between consecutive runs' first slides (>= n) */
+    int64_t par_stride;    /* floats */
+    int64_t image_stride;  /* bytes, >= moc_w1_image_bytes(D, dtype) */
+} moc_runs_t;
+/* M: run 0's tensors.  ws->W2_alt: [n_runs, 4, H].  ws->tile_ws required (the tile-record step is the only one batched). */
+int moc_train_steps_runs(const moc_batch_t* B, const moc_meta_t* M, const moc_runs_t* R, const moc_meta_ws_t* ws,
+                         const int64_t* labels, int slide0, int n, uint32_t use_bits, moc_stream_t stream);
+
 /* a10-a14 for ONE slide without the update: forward, pooling, loss (ws->loss/pooled/pred) and
  * the gradients of that loss w.r.t. the four parameter tensors, written (not accumulated) to
  * M->g_*.  The data-parallel step all-reduces them and calls moc_adam_step. */

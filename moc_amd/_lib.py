@@ -55,6 +55,10 @@ class MocMetaWs(C.Structure):
                                   "loss", "pred", "pair_dh", "W2_alt", "pair_row", "n_pair", "tile_ws")] + [("tile_ws_bytes", C.c_int64)]
 
 
+class MocRuns(C.Structure):
+    _fields_ = [("n_runs", C.c_int32), ("slide_stride", C.c_int32), ("par_stride", C.c_int64), ("image_stride", C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/moc_hip.h declares
 _BP, _MP, _WP = C.POINTER(MocBatch), C.POINTER(MocMeta), C.POINTER(MocMetaWs)
 SIGNATURES = {
@@ -83,6 +87,7 @@ SIGNATURES = {
     "moc_senet_backward": (C.c_int, [_p, C.c_int, C.c_int64, C.c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "moc_adam_step": (C.c_int, [_MP, C.c_float, _p]),
     "moc_train_steps": (C.c_int, [_BP, _MP, _WP, _p, C.c_int, C.c_int, C.c_uint32, _p]),
+    "moc_train_steps_runs": (C.c_int, [_BP, _MP, C.POINTER(MocRuns), _WP, _p, C.c_int, C.c_int, C.c_uint32, _p]),
     "moc_step_graph_workspace_bytes": (C.c_size_t, [C.c_int]),
     "moc_step_graph_create": (C.c_int, [_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "moc_step_graph_destroy": (C.c_int, [_p]),

@@ -64,6 +64,7 @@ __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float 
 // every tile -- checked; otherwise (and for more than 64 candidates) the kernel falls back to the full scores, which the
 // forward still writes.  Same rows, same (value desc, row asc) order, same sum: same bits.
 constexpr int TILE_R = 4;
+constexpr int MOC_MAX_RUNS = 16;        // meta-learners one launch can serve (moc_train_steps_runs)
 constexpr int MOC_TILE_PATH_RECORDS = 1000001, MOC_TILE_PATH_FULL = 1000002;   // left in ws->n_pair[0] by the tile-record step
 struct TileWs {
     float4* lam;                 // [slots] gates of the record's row
@@ -141,7 +142,55 @@ struct FwdArgs {
     TileWs tile;
     int tile_on, tile_cap;          // tile_cap = ceil(rows of the slide / 16)
     int64_t tile_slot0;             // first slot of the slide's region
+    // batched runs (round 4; n_runs > 0): ONE launch serves n_runs independent meta-learners, grid.y = run.  Run r works on
+    // slide slide0 + r * slide_stride with its own parameters, par_stride floats (W2: w2_stride; operand image: img_stride
+    // bytes) behind run 0's; the per-run scalars the host knows come as arrays (kernel arguments, indexed by the run)
+    int n_runs, slide_stride;
+    int64_t par_stride, w2_stride, img_stride;
+    int64_t base_r[MOC_MAX_RUNS], tile_slot0_r[MOC_MAX_RUNS];
+    int32_t tile_cap_r[MOC_MAX_RUNS];
 };
+
+// An entry of an array inside the kernel's (single, by-value) argument struct, read straight from the kernel-argument
+// segment by a uniform index: indexing the struct itself with a runtime index makes hipcc copy all of it to scratch.
+template <typename T>
+__device__ __forceinline__ T kernarg_at(size_t off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const char* kp_t;
+    kp_t p = (kp_t)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(__attribute__((address_space(4))) const T*)(p + off);
+#else
+    return T();
+#endif
+}
+
+// what a forward workgroup works on: its slide and, with batched runs, its run's tensors (the argument block is not modified)
+struct FwdRun {
+    int b;
+    int64_t base, tile_slot0;
+    int tile_cap;
+    const unsigned char* W1img;
+    const float *W2, *b1, *b2;
+};
+__device__ __forceinline__ FwdRun fwd_run_setup(const FwdArgs& a) {
+    FwdRun r;
+    r.W1img = a.W1img; r.W2 = a.W2; r.b1 = a.b1; r.b2 = a.b2; r.tile_slot0 = a.tile_slot0; r.tile_cap = a.tile_cap;
+    if (a.n_runs > 0) {
+        const int run = blockIdx.y;
+        r.b = a.slide0 + run * a.slide_stride;
+        r.base = kernarg_at<int64_t>(offsetof(FwdArgs, base_r) + 8 * (size_t)run);
+        r.tile_slot0 = kernarg_at<int64_t>(offsetof(FwdArgs, tile_slot0_r) + 8 * (size_t)run);
+        r.tile_cap = kernarg_at<int32_t>(offsetof(FwdArgs, tile_cap_r) + 4 * (size_t)run);
+        r.W1img += (int64_t)run * a.img_stride;
+        r.W2 += (int64_t)run * a.w2_stride;
+        r.b1 += (int64_t)run * a.par_stride;
+        r.b2 += (int64_t)run * a.par_stride;
+    } else {
+        r.b = a.slide0 + blockIdx.y;
+        r.base = a.base_host >= 0 ? a.base_host : a.row_off[r.b];
+    }
+    return r;
+}
 
 // the row of a selected slot o in whichever array holds its candidate scores: column k of it is ptr[k * stride]
 __device__ __forceinline__ const float* cand_row(const FwdArgs& a, int64_t base, int o) {
@@ -201,10 +250,11 @@ __device__ __forceinline__ void w1_image_store(int dt, unsigned char* img, int D
     else if (dt == MOC_BF16) w1_image_store_half<false>(img, D, h, d, w);
     else w1_image_store_f32(img, D, h, d, w);
 }
-__global__ __launch_bounds__(256) void w1_image_kernel(const float* W1, int D, unsigned char* img, int dt) {
-    const int e = blockIdx.x * 256 + threadIdx.x;       // grid = H*D/256
+__global__ __launch_bounds__(256) void w1_image_kernel(const float* W1, int D, unsigned char* img, int dt, int64_t par_stride = 0,
+                                                       int64_t img_stride = 0) {
+    const int e = blockIdx.x * 256 + threadIdx.x;       // grid = (H*D/256, runs)
     const int h = e / D, d = e - h * D;
-    w1_image_store(dt, img, D, h, d, W1[e]);
+    w1_image_store(dt, img + (int64_t)blockIdx.y * img_stride, D, h, d, W1[(int64_t)blockIdx.y * par_stride + e]);
 }
 
 // fp32 bags: one quarter's chain joins the running sum (first quarter: taken as it is), the chain starts over
@@ -223,8 +273,9 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
     __shared__ float Hs[16][H + 1];
     __shared__ float Gs[16][4];
     __shared__ float W2s[4 * H];
-    const int b = a.slide0 + blockIdx.y;
-    const int64_t base = a.base_host >= 0 ? a.base_host : a.row_off[b];
+    const FwdRun fr = fwd_run_setup(a);
+    const int b = fr.b;
+    const int64_t base = fr.base;
     const int S = a.n_sel[b];
     const int row0 = blockIdx.x * 16;
     if (row0 >= S) return;
@@ -242,9 +293,9 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
         cand_class_scores(a, cd, c, m1, rden, pre_c[0], pre_c[1]);
         cand_row_scores(a, cd, pre_c[2], pre_c[3]);
     }
-    const float w2_pre = a.W2[threadIdx.x & 255];
-    const float bias = a.b1[wave * 16 + (lane & 15)];
-    const float b2_pre = a.b2[threadIdx.x & 3];
+    const float w2_pre = fr.W2[threadIdx.x & 255];
+    const float bias = fr.b1[wave * 16 + (lane & 15)];
+    const float b2_pre = fr.b2[threadIdx.x & 3];
     int64_t rid_e = 0;                                               // tile records: the bag row of this thread's (row, class)
     if (a.tile_on) rid_e = a.sel_row[base + min(row0 + (int)(threadIdx.x & 15), S - 1)];
     // The 16 x D tile of x goes through LDS once per workgroup: wave w fetches rows 4w..4w+3 with
@@ -277,7 +328,7 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
         if constexpr (BF16) {
             // this unit's W1 image: 16 (or 8) k-steps x 3 terms, all requested before the first MFMA
             uint4 wv[16 * 3];
-            const uint4* wi = reinterpret_cast<const uint4*>(a.W1img) + ((size_t)wave * KST + (size_t)u * ksteps) * 3 * 64 + lane;
+            const uint4* wi = reinterpret_cast<const uint4*>(fr.W1img) + ((size_t)wave * KST + (size_t)u * ksteps) * 3 * 64 + lane;
 #pragma unroll
             for (int q = 0; q < 16 * 3; ++q) if (q < ksteps * 3) wv[q] = wi[q * 64];
             if (lane < cpr) {
@@ -299,7 +350,7 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
             }
         } else {
             uint4 wv[16];
-            const uint4* wi = reinterpret_cast<const uint4*>(a.W1img) + ((size_t)wave * KST + (size_t)u * ksteps) * 64 + lane;
+            const uint4* wi = reinterpret_cast<const uint4*>(fr.W1img) + ((size_t)wave * KST + (size_t)u * ksteps) * 64 + lane;
 #pragma unroll
             for (int q = 0; q < 16; ++q) if (q < ksteps) wv[q] = wi[q * 64];
             if (lane < cpr) {
@@ -383,7 +434,7 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
         if (a.use_bits & 8u) v = moc_fadd(v, moc_fmul(Gs[r][3], pre_c[3]));
         const float4 lam4 = {Gs[r][0], Gs[r][1], Gs[r][2], Gs[r][3]};
         const float4 sc4 = {pre_c[0], pre_c[1], pre_c[2], pre_c[3]};
-        tile_emit(a.tile, a.tile_slot0 / TILE_R + (int64_t)c * a.tile_cap + blockIdx.x, ok, v, row0 + r, rid_e, lam4, sc4);
+        tile_emit(a.tile, fr.tile_slot0 / TILE_R + (int64_t)c * fr.tile_cap + blockIdx.x, ok, v, row0 + r, rid_e, lam4, sc4);
     }
     MOC_STAMP(2);
 }
@@ -414,8 +465,9 @@ __global__ __launch_bounds__(1024) void meta_forward_ksplit_kernel(FwdArgs a) {
     float (*Hs)[H + 1] = reinterpret_cast<float (*)[H + 1]>(part + 4 * 16 * FKS_PSTR);
     float (*Gs)[4] = reinterpret_cast<float (*)[4]>(reinterpret_cast<float*>(Hs) + 16 * (H + 1));
     float* W2s = reinterpret_cast<float*>(Gs) + 16 * 4;
-    const int b = a.slide0 + blockIdx.y;
-    const int64_t base = a.base_host >= 0 ? a.base_host : a.row_off[b];
+    const FwdRun fr = fwd_run_setup(a);
+    const int b = fr.b;
+    const int64_t base = fr.base;
     const int S = a.n_sel[b];
     const int row0 = blockIdx.x * 16;
     if (row0 >= S) return;
@@ -435,7 +487,7 @@ __global__ __launch_bounds__(1024) void meta_forward_ksplit_kernel(FwdArgs a) {
     // W1 image of (hidden tile, quarter): D / 64 fragments of 1 KiB.  (rid >> 63 is zero: the address is made to depend on
     // the row id so that hipcc cannot hoist these loads above the row id's wait -- they must queue BEHIND the rows.)
     constexpr int QS = D / 64;
-    const uint4* wi = reinterpret_cast<const uint4*>(a.W1img) + ((size_t)ht * (D / 16) + (size_t)kq * QS) * 64 + lane + (rid >> 63);
+    const uint4* wi = reinterpret_cast<const uint4*>(fr.W1img) + ((size_t)ht * (D / 16) + (size_t)kq * QS) * 64 + lane + (rid >> 63);
     // (the rows first: loads return in issue order, and the tile must be in LDS before the first MFMA, while the image
     // fragments -- 128 KiB per workgroup through one CU's 64 B/clk -- may keep arriving under the chain)
     uint4 xv[cpl];
@@ -472,9 +524,9 @@ __global__ __launch_bounds__(1024) void meta_forward_ksplit_kernel(FwdArgs a) {
         pre_c[2] = cd[(int64_t)(2 * C) * a.stride];
         pre_c[3] = cd[(int64_t)(2 * C + 1) * a.stride];
     }
-    const float w2_pre = a.W2[t & 255];
-    const float bias = a.b1[t & 63];
-    const float b2_pre = a.b2[t & 3];
+    const float w2_pre = fr.W2[t & 255];
+    const float bias = fr.b1[t & 63];
+    const float b2_pre = fr.b2[t & 3];
     int64_t rid_e = 0;                                       // tile records: the bag row of this thread's (row, class)
     if (a.tile_on) rid_e = a.sel_row[base + min(row0 + er, S - 1)];
     __builtin_amdgcn_sched_barrier(0);                       // (hipcc otherwise sinks these requests below the chain)
@@ -535,7 +587,7 @@ __global__ __launch_bounds__(1024) void meta_forward_ksplit_kernel(FwdArgs a) {
         if (a.tile_on) {
             const float4 lam4 = {Gs[er][0], Gs[er][1], Gs[er][2], Gs[er][3]};
             const float4 sc4 = {pre_c[0], pre_c[1], pre_c[2], pre_c[3]};
-            tile_emit(a.tile, a.tile_slot0 / TILE_R + (int64_t)ec * a.tile_cap + blockIdx.x, e_ok, v, row0 + er, rid_e, lam4, sc4);
+            tile_emit(a.tile, fr.tile_slot0 / TILE_R + (int64_t)ec * fr.tile_cap + blockIdx.x, e_ok, v, row0 + er, rid_e, lam4, sc4);
         }
     }
     MOC_STAMP(2);
@@ -1784,33 +1836,55 @@ struct TileStepArgs {
     const float* gates;
     const int64_t* sel_row;
     int64_t stride;
+    // ---- batched runs (n_runs > 0): grid.z = run; run r steps the meta-learner whose tensors lie par_stride floats (W2 in:
+    // w2_stride, W2 out: w2out_stride, operand image: img_stride bytes) behind run 0's, on slide slide0 + r * slide_stride
+    int n_runs, slide_stride;
+    int64_t par_stride, w2_stride, w2out_stride, img_stride;
+    int64_t base_r[MOC_MAX_RUNS], slot0_r[MOC_MAX_RUNS];
+    int32_t cap_r[MOC_MAX_RUNS], ntb_r[MOC_MAX_RUNS];
 };
 
 template <int VQ>
-__global__ __launch_bounds__(256) void pool_w1_step_tiles_kernel(TileStepArgs a) {
+__global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     {   // every cache line of the arguments, requested side by side, one wait
-        static_assert(sizeof(TileStepArgs) <= 512, "TileStepArgs outgrew the lines touched here");
+        static_assert(sizeof(TileStepArgs) <= 1024, "TileStepArgs outgrew the lines touched here");
 #if defined(__HIP_DEVICE_COMPILE__)
         auto ka = __builtin_amdgcn_kernarg_segment_ptr();
         unsigned k0, k1, k2, k3, k4, k5, k6, k7;
         asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\t"
                      "s_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\t"
-                     "s_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\ts_waitcnt lgkmcnt(0)"
+                     "s_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\t"
+                     "s_load_dword %0, %8, 0x200\n\ts_load_dword %1, %8, 0x240\n\ts_load_dword %2, %8, 0x280\n\t"
+                     "s_load_dword %3, %8, 0x2c0\n\ts_load_dword %4, %8, 0x300\n\ts_load_dword %5, %8, 0x340\n\t"
+                     "s_load_dword %6, %8, 0x380\n\ts_load_dword %7, %8, 0x3c0\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3), "=&s"(k4), "=&s"(k5), "=&s"(k6), "=&s"(k7)
                      : "s"(ka) : "memory");
 #endif
     }
-    const int b = a.slide0, C = a.C, K = a.K, D = a.D, PS_CAP = a.PS_CAP;
+    // batched runs: this workgroup's run -- its slide, its region of the records, the offsets of its tensors (the argument
+    // block itself is not modified and its arrays are read through kernarg_at: either would send all of it to scratch)
+    int b = a.slide0;
+    int64_t base = a.base, slot0 = a.slot0, po = 0, w2o = 0, w2outo = 0, imgo = 0;
+    int cap = a.cap, ntile_bound = a.ntile_bound;
+    if (a.n_runs > 0) {
+        const int run = blockIdx.z;
+        b += run * a.slide_stride;
+        base = kernarg_at<int64_t>(offsetof(TileStepArgs, base_r) + 8 * (size_t)run);
+        slot0 = kernarg_at<int64_t>(offsetof(TileStepArgs, slot0_r) + 8 * (size_t)run);
+        cap = kernarg_at<int32_t>(offsetof(TileStepArgs, cap_r) + 4 * (size_t)run);
+        ntile_bound = kernarg_at<int32_t>(offsetof(TileStepArgs, ntb_r) + 4 * (size_t)run);
+        po = (int64_t)run * a.par_stride; w2o = (int64_t)run * a.w2_stride; w2outo = (int64_t)run * a.w2out_stride;
+        imgo = (int64_t)run * a.img_stride;
+    }
+    const int C = a.C, K = a.K, D = a.D, PS_CAP = a.PS_CAP;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int cb = blockIdx.x, h = blockIdx.y;
-    const bool wg0 = cb == 0 && h == 0;
+    const bool wg0 = cb == 0 && h == 0;                                              // (of its run)
     constexpr int CL = 64;                                                            // candidates per class
     MOC_STAMP(10);
     MOC_STAMP_MIN(33);
     MOC_STAMP_MAX(34);
-    const int64_t base = a.base, slot0 = a.slot0;
-    const int cap = a.cap, ntile_bound = a.ntile_bound;
     // ---- round trip 1, requested before anything else: the keys of this wave's first class (wave w: classes w, w + 4, ...)
     unsigned long long key[VQ];
     uint32_t rho[VQ / 4];
@@ -1840,13 +1914,13 @@ __global__ __launch_bounds__(256) void pool_w1_step_tiles_kernel(TileStepArgs a)
         else if (wg0 && t >= 128 && t < 132) tail = H + 4 * H + (t - 128);           // b2[i]: wave 2
     }
     float w2v = 0.f;
-    if (t < 4) w2v = a.W2[t * H + h];
+    if (t < 4) w2v = a.W2[w2o + t * H + h];
     if (a.apply_adam) {
-        const int e = h * D + d;
+        const int64_t e = po + h * D + d;
         pw = a.W1[e]; pm = a.m_W1[e]; pv = a.v_W1[e];
-        if (tail >= H + 4 * H) { const int i = tail - 5 * H; pT = a.b2[i]; pTm = a.m_b2[i]; pTv = a.v_b2[i]; }
-        else if (tail >= H) { const int i = tail - H; pTm = a.m_W2[i]; pTv = a.v_W2[i]; }
-        else if (tail >= 0) { pT = a.b1[tail]; pTm = a.m_b1[tail]; pTv = a.v_b1[tail]; }
+        if (tail >= H + 4 * H) { const int64_t i = po + tail - 5 * H; pT = a.b2[i]; pTm = a.m_b2[i]; pTv = a.v_b2[i]; }
+        else if (tail >= H) { const int64_t i = po + tail - H; pTm = a.m_W2[i]; pTv = a.v_W2[i]; }
+        else if (tail >= 0) { pT = a.b1[po + tail]; pTm = a.m_b1[po + tail]; pTv = a.v_b1[po + tail]; }
     }
     MOC_STAMP(19);
     AdamCoef ak = a.adam;
@@ -1975,7 +2049,10 @@ __global__ __launch_bounds__(256) void pool_w1_step_tiles_kernel(TileStepArgs a)
     MOC_STAMP(13);
     bool fast = true;
     for (int c = 0; c < C; ++c) fast = fast && flagc[c] == 0;
-    if (wg0 && t == 0 && a.n_pair) *a.n_pair = fast ? MOC_TILE_PATH_RECORDS : MOC_TILE_PATH_FULL;   // (which path ran: tests, diagnostics)
+    if (wg0 && t == 0 && a.n_pair) {                     // (which path ran: tests, diagnostics; with runs: the largest code of any)
+        if (a.n_runs > 0) atomicMax(a.n_pair, fast ? MOC_TILE_PATH_RECORDS : MOC_TILE_PATH_FULL);
+        else *a.n_pair = fast ? MOC_TILE_PATH_RECORDS : MOC_TILE_PATH_FULL;
+    }
     if (!fast) {
         // ---- fall-back: the same bound T0 (a valid one: K group maxima are K scores >= T0) over ALL mixed scores of the
         // slide.  Compact code, not fast code: it runs when a tile holds more than TILE_R of the candidates.
@@ -2179,16 +2256,16 @@ __global__ __launch_bounds__(256) void pool_w1_step_tiles_kernel(TileStepArgs a)
     }
     const float gs = ak.grad_scale;
     {
-        const int e = h * D + d;
+        const int64_t e = po + h * D + d;
         adam_update(pw, pm, pv, gr * gs, ak);
         a.W1[e] = pw; a.m_W1[e] = pm; a.v_W1[e] = pv;
-        w1_image_store(a.img_dt, a.W1img, D, h, d, pw);
+        w1_image_store(a.img_dt, a.W1img + imgo, D, h, d, pw);
     }
     if (tail >= 0) {
         adam_update(pT, pTm, pTv, gt * gs, ak);
-        if (tail >= H + 4 * H) { const int i = tail - 5 * H; a.b2[i] = pT; a.m_b2[i] = pTm; a.v_b2[i] = pTv; }
-        else if (tail >= H) { const int i = tail - H; a.W2out[i] = pT; a.m_W2[i] = pTm; a.v_W2[i] = pTv; }
-        else { a.b1[tail] = pT; a.m_b1[tail] = pTm; a.v_b1[tail] = pTv; }
+        if (tail >= H + 4 * H) { const int64_t i = po + tail - 5 * H; a.b2[i] = pT; a.m_b2[i] = pTm; a.v_b2[i] = pTv; }
+        else if (tail >= H) { const int i = tail - H; a.W2out[w2outo + i] = pT; a.m_W2[po + i] = pTm; a.v_W2[po + i] = pTv; }
+        else { a.b1[po + tail] = pT; a.m_b1[po + tail] = pTm; a.v_b1[po + tail] = pTv; }
     }
     MOC_STAMP(18);
     MOC_STAMP_MAX(35);
@@ -2755,12 +2832,16 @@ int s_bound(const moc_batch_t* B) {
 
 bool tiles_ok(const moc_batch_t* B, const moc_meta_ws_t* ws);
 
-// emit_tiles: the one-launch step over tile records follows (training step of one slide): leave the records
+// emit_tiles: the one-launch step over tile records follows (training step of one slide): leave the records.
+// runs != nullptr: the training forward of runs->n_runs meta-learners in one launch (moc_train_steps_runs), `w2_cur` /
+// `w2_stride` = where their current W2 lives.
 int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, int slide0, int n,
-                   uint32_t use_bits, hipStream_t s, bool emit_tiles = false) {
+                   uint32_t use_bits, hipStream_t s, bool emit_tiles = false, const moc_runs_t* runs = nullptr,
+                   int64_t w2_stride = 0) {
     FwdArgs a;
     a.tile_on = 0; a.tile_cap = 0; a.tile_slot0 = 0;
     a.tile = TileWs();
+    a.n_runs = 0; a.slide_stride = 0; a.par_stride = a.w2_stride = a.img_stride = 0;
     a.X = (const unsigned char*)B->X; a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel;
     a.cand = B->cand; a.W1 = M->W1; a.b1 = M->b1; a.W2 = M->W2; a.b2 = M->b2;
     a.W1img = (const unsigned char*)M->W1_image;
@@ -2783,6 +2864,47 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
         a.stats = B->stats; a.sel_idx = B->sel_idx;
     }
     dim3 grid(moc_cdiv(s_bound(B), 16), n);
+    if (runs) {                                            // one training slide per run, grid.y = run
+        MOC_REQUIRE(n == 1 && a.tile_on, "moc_train_steps_runs: the batched forward needs the tile-record step");
+        a.n_runs = runs->n_runs; a.slide_stride = runs->slide_stride;
+        a.par_stride = runs->par_stride; a.img_stride = runs->image_stride; a.w2_stride = w2_stride;
+        for (int r = 0; r < runs->n_runs; ++r) {
+            const int sl = slide0 + r * runs->slide_stride;
+            a.base_r[r] = B->row_off_host[sl];
+            a.tile_cap_r[r] = moc_cdiv(B->row_off_host[sl + 1] - B->row_off_host[sl], 16);
+            a.tile_slot0_r[r] = ((B->row_off_host[sl] >> 4) + sl) * (int64_t)B->C * TILE_R;
+        }
+        grid.y = runs->n_runs;
+        // fp32 bags: the sixteen-wave kernel is built for the latency of ONE tile per CU; with many runs there are more
+        // tiles than the chip holds sixteen-wave workgroups (two per CU), and the four-wave kernel -- the same bits
+        // (tests: MOC_FORWARD_FOUR_WAVES) -- packs seven to a CU and keeps the matrix cores fed
+        static const int fwd4_env = getenv("MOC_RUNS_FWD4") ? atoi(getenv("MOC_RUNS_FWD4")) : -1;
+        const bool four = fwd4_env >= 0 ? fwd4_env != 0 : (int64_t)grid.x * grid.y > 512;
+        if (B->dtype == MOC_F32 && four && B->C <= 16) {
+            meta_forward_kernel<false><<<grid, 256, 0, s>>>(a);
+            MOC_CHECK_LAUNCH("moc_meta_forward(runs, four waves)");
+            return MOC_OK;
+        }
+        if (B->dtype == MOC_F32) {
+            MOC_REQUIRE(B->D <= 1024 && B->C <= 64, "moc_train_steps_runs: fp32 bags need D <= 1024, C <= 64");
+            static bool attr_r = false;
+            if (!attr_r) {
+                (void)hipFuncSetAttribute((const void*)meta_forward_ksplit_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, fks_lds_bytes(768));
+                (void)hipFuncSetAttribute((const void*)meta_forward_ksplit_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, fks_lds_bytes(1024));
+                attr_r = true;
+            }
+            const int lds = fks_lds_bytes(B->D);
+            switch (B->D / 256) {
+                case 1: meta_forward_ksplit_kernel<1, false><<<grid, 1024, lds, s>>>(a); break;
+                case 2: meta_forward_ksplit_kernel<2, false><<<grid, 1024, lds, s>>>(a); break;
+                case 3: meta_forward_ksplit_kernel<3, false><<<grid, 1024, lds, s>>>(a); break;
+                default: meta_forward_ksplit_kernel<4, false><<<grid, 1024, lds, s>>>(a); break;
+            }
+        } else if (B->dtype == MOC_F16) meta_forward_kernel<true, true><<<grid, 256, 0, s>>>(a);
+        else meta_forward_kernel<true><<<grid, 256, 0, s>>>(a);
+        MOC_CHECK_LAUNCH("moc_meta_forward(runs)");
+        return MOC_OK;
+    }
     static const int fwd_variant = getenv("MOC_FORWARD_EVAL") ? atoi(getenv("MOC_FORWARD_EVAL")) : 128;   // diagnostic: 64 = the 64-row kernel
     if (n >= 4 && (B->D * moc_elem_size(B->dtype)) % 512 == 0 && s_bound(B) >= 1024 && fwd_variant == 128 &&
         !(B->flags & MOC_FORWARD_ROWS64)) {
@@ -2991,6 +3113,57 @@ void fused_step_attrs() {
     done = true;
 }
 
+// the argument block of pool_w1_step_tiles_kernel for slide `slide` of B (one run)
+void tile_region(const moc_batch_t* B, int slide, int64_t* slot0, int* tcap, int* tb) {
+    const int64_t base = B->row_off_host[slide], seg = B->row_off_host[slide + 1] - base;
+    // the slide's region: cap tiles per class; the kernel's loads are issued before n_sel is known and clamped to the
+    // tiles the slide can have at all (at most s_bound selected rows)
+    *tcap = moc_cdiv(seg, 16) > 0 ? moc_cdiv(seg, 16) : 1;
+    const int tb_all = moc_cdiv(s_bound(B), 16);
+    *tb = *tcap < tb_all ? *tcap : tb_all;
+    *slot0 = ((base >> 4) + slide) * (int64_t)B->C * TILE_R;
+}
+
+TileStepArgs tile_step_args(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels, int slide,
+                            uint32_t use_bits, const AdamCoef& k, float* W2out, int apply_adam, const StepTab* tab) {
+    const TileWs T = tile_carve(ws->tile_ws, tile_slots(B->total_rows, B->n_slides, B->C));
+    TileStepArgs ta = {};
+    ta.tkey = T.key; ta.trho = T.rho; ta.trid = T.rid; ta.tlam = T.lam; ta.tsc = T.sc;
+    tile_region(B, slide, &ta.slot0, &ta.cap, &ta.ntile_bound);
+    ta.C = B->C; ta.K = B->topk; ta.D = B->D; ta.slide0 = slide; ta.PS_CAP = B->C <= 8 ? PS_CAP_MAX : PS_CAP_MAX / 2;
+    ta.xdt = B->dtype; ta.n_sel = B->n_sel; ta.labels = labels;
+    ta.W1 = M->W1; ta.m_W1 = M->m_W1; ta.v_W1 = M->v_W1; ta.W2 = M->W2;
+    ta.b1 = M->b1; ta.m_b1 = M->m_b1; ta.v_b1 = M->v_b1; ta.b2 = M->b2; ta.m_b2 = M->m_b2; ta.v_b2 = M->v_b2;
+    ta.m_W2 = M->m_W2; ta.v_W2 = M->v_W2;
+    ta.base = B->row_off_host[slide]; ta.adam = k;
+    if (tab) { ta.adam_tab = tab->tab; ta.adam_ctr = tab->ctr; ta.adam_pos = tab->pos; }
+    ta.apply_adam = apply_adam; ta.use_bits = use_bits; ta.img_dt = B->dtype;
+    ta.H1 = ws->H1; ta.X = (const unsigned char*)B->X;
+    ta.pooled_out = ws->pooled; ta.topk_idx_out = ws->topk_idx; ta.topk_cnt_out = ws->topk_cnt;
+    ta.loss = ws->loss; ta.pred = ws->pred; ta.n_pair = ws->n_pair;
+    ta.W1img = (unsigned char*)M->W1_image; ta.W2out = W2out;
+    ta.g_W1 = M->g_W1; ta.g_b1 = M->g_b1; ta.g_W2 = M->g_W2; ta.g_b2 = M->g_b2;
+    ta.mixed_in = ws->mixed; ta.cand = B->cand; ta.gates = ws->gates; ta.sel_row = B->sel_row; ta.stride = B->total_rows;
+    return ta;
+}
+
+// launches it for `runs` meta-learners (grid.z); the largest tile bound of any run picks the keys per lane
+int launch_tile_step(const moc_batch_t* B, const TileStepArgs& ta, int runs, hipStream_t s) {
+    const size_t sm = tiles_step_smem(B, ta.PS_CAP);
+    const dim3 grid(B->D / 256, H, runs);
+    int tb = ta.ntile_bound;
+    for (int r = 0; r < ta.n_runs; ++r) tb = ta.ntb_r[r] > tb ? ta.ntb_r[r] : tb;
+#define MOC_TILES_LAUNCH(VQ) pool_w1_step_tiles_kernel<VQ><<<grid, 256, sm, s>>>(ta)
+    const int vq = moc_cdiv((int64_t)tb * TILE_R, 64);                 // keys per lane of a class wave
+    if (vq <= 4) MOC_TILES_LAUNCH(4);
+    else if (vq <= 8) MOC_TILES_LAUNCH(8);
+    else if (vq <= 12) MOC_TILES_LAUNCH(12);
+    else MOC_TILES_LAUNCH(16);
+#undef MOC_TILES_LAUNCH
+    MOC_CHECK_LAUNCH("moc_fused_step(tiles)");
+    return MOC_OK;
+}
+
 int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels,
                       int slide, uint32_t use_bits, const AdamCoef& k, float* W2out, hipStream_t s,
                       int apply_adam = 1, const P2pArgs* x = nullptr, const StepTab* tab = nullptr) {
@@ -3038,40 +3211,8 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
     const int cap = B->C <= 8 ? PS_CAP_MAX : PS_CAP_MAX / 2;
     if (g.x.world <= 1 && tiles_ok(B, ws)) {               // over the forward's tile records (the forward was told to leave them)
         fused_step_attrs();
-        const TileWs T = tile_carve(ws->tile_ws, tile_slots(B->total_rows, B->n_slides, B->C));
-        // the slide's region: cap tiles per class; the kernel's loads are issued before n_sel is known and clamped to the
-        // tiles the slide can have at all (at most s_bound selected rows)
-        const int tcap = moc_cdiv(a.seg_host, 16) > 0 ? moc_cdiv(a.seg_host, 16) : 1;
-        const int tb_all = moc_cdiv(s_bound(B), 16);
-        const int tb = tcap < tb_all ? tcap : tb_all;
-        TileStepArgs ta = {};
-        ta.tkey = T.key; ta.trho = T.rho; ta.trid = T.rid; ta.tlam = T.lam; ta.tsc = T.sc;
-        ta.slot0 = ((a.base_host >> 4) + slide) * (int64_t)B->C * TILE_R;
-        ta.cap = tcap; ta.ntile_bound = tb; ta.C = B->C; ta.K = B->topk; ta.D = B->D; ta.slide0 = slide; ta.PS_CAP = cap;
-        ta.xdt = B->dtype; ta.n_sel = B->n_sel; ta.labels = labels;
-        ta.W1 = M->W1; ta.m_W1 = M->m_W1; ta.v_W1 = M->v_W1; ta.W2 = M->W2;
-        ta.b1 = M->b1; ta.m_b1 = M->m_b1; ta.v_b1 = M->v_b1; ta.b2 = M->b2; ta.m_b2 = M->m_b2; ta.v_b2 = M->v_b2;
-        ta.m_W2 = M->m_W2; ta.v_W2 = M->v_W2;
-        ta.base = a.base_host; ta.adam = k;
-        if (tab) { ta.adam_tab = tab->tab; ta.adam_ctr = tab->ctr; ta.adam_pos = tab->pos; }
-        ta.apply_adam = apply_adam; ta.use_bits = use_bits; ta.img_dt = B->dtype;
-        ta.H1 = ws->H1; ta.X = (const unsigned char*)B->X;
-        ta.pooled_out = ws->pooled; ta.topk_idx_out = ws->topk_idx; ta.topk_cnt_out = ws->topk_cnt;
-        ta.loss = ws->loss; ta.pred = ws->pred; ta.n_pair = ws->n_pair;
-        ta.W1img = (unsigned char*)M->W1_image; ta.W2out = W2out;
-        ta.g_W1 = M->g_W1; ta.g_b1 = M->g_b1; ta.g_W2 = M->g_W2; ta.g_b2 = M->g_b2;
-        ta.mixed_in = ws->mixed; ta.cand = B->cand; ta.gates = ws->gates; ta.sel_row = B->sel_row; ta.stride = B->total_rows;
-        const size_t sm = tiles_step_smem(B, cap);
-        const dim3 grid(B->D / 256, H);
-#define MOC_TILES_LAUNCH(VQ) pool_w1_step_tiles_kernel<VQ><<<grid, 256, sm, s>>>(ta)
-        const int vq = moc_cdiv((int64_t)tb * TILE_R, 64);                 // keys per lane of a class wave
-        if (vq <= 4) MOC_TILES_LAUNCH(4);
-        else if (vq <= 8) MOC_TILES_LAUNCH(8);
-        else if (vq <= 12) MOC_TILES_LAUNCH(12);
-        else MOC_TILES_LAUNCH(16);
-#undef MOC_TILES_LAUNCH
-        MOC_CHECK_LAUNCH("moc_fused_step(tiles)");
-        return MOC_OK;
+        TileStepArgs ta = tile_step_args(B, M, ws, labels, slide, use_bits, k, W2out, apply_adam, tab);
+        return launch_tile_step(B, ta, 1, s);
     }
     const size_t smem = fused_step_smem(B, cap);
     static bool attr_set = false;
@@ -3312,6 +3453,58 @@ extern "C" int moc_train_steps(const moc_batch_t* B, const moc_meta_t* M, const 
         if (int rc = launch_forward(B, M, ws, b, 1, use_bits, s)) return rc;
         if (int rc = launch_pool_finish(B, M, ws, labels, b, 1, 1, 1, use_bits, k, s)) return rc;
         if (int rc = launch_w1(B, M, ws, 1, k, s, fused_ok(B, 1))) return rc;
+    }
+    return MOC_OK;
+}
+
+// ------------------------------------------------------------------ batched runs: R meta-learners, lockstep
+// The reference's real workload is folds x shots of the SAME loop as independent processes (scripts/moc_train.sh:11-31), and
+// one run is a chain of dependent 17-us steps that leaves most of the GPU idle.  Here ONE forward launch and ONE step
+// launch serve R runs: grid.y / grid.z = run.  Every run stays the exact recurrence of moc_train_steps -- its own slides,
+// parameters, Adam moments; the same kernels, the same operation order: bit-identical to running it alone.
+extern "C" int moc_train_steps_runs(const moc_batch_t* B, const moc_meta_t* M, const moc_runs_t* R, const moc_meta_ws_t* ws,
+                                    const int64_t* labels, int slide0, int n, uint32_t use_bits, moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_train_steps_runs")) return rc;
+    if (int rc = check_meta(B, M, ws, "moc_train_steps_runs", true, false)) return rc;
+    MOC_REQUIRE(R && R->n_runs >= 1 && R->n_runs <= MOC_MAX_RUNS, "moc_train_steps_runs: 1 .. %d runs", MOC_MAX_RUNS);
+    MOC_REQUIRE(labels && slide0 >= 0 && n >= 1 && R->slide_stride >= n &&
+                slide0 + n + (R->n_runs - 1) * R->slide_stride <= B->n_slides, "moc_train_steps_runs: bad labels/slide range");
+    MOC_REQUIRE(R->par_stride >= (int64_t)H * B->D + H + 4 * H + 4 && R->image_stride >= (int64_t)moc_w1_image_bytes(B->D, B->dtype),
+                "moc_train_steps_runs: parameter / image stride smaller than one meta-learner");
+    MOC_REQUIRE(tiles_ok(B, ws), "moc_train_steps_runs: shape outside the tile-record step (C <= 16, K <= 16, C*K <= 64, selected rows <= 4096, "
+                                 "D <= 1024, ws->tile_ws and W2_alt set)");
+    hipStream_t s = (hipStream_t)stream;
+    fused_step_attrs();
+    w1_image_kernel<<<dim3(H * B->D / 256, R->n_runs), 256, 0, s>>>(M->W1, B->D, (unsigned char*)M->W1_image, B->dtype, R->par_stride,
+                                                                    R->image_stride);
+    MOC_CHECK_LAUNCH("moc_w1_image(runs)");
+    moc_meta_t Mt = *M;
+    float* cur = M->W2;
+    float* nxt = ws->W2_alt;
+    int64_t cur_stride = R->par_stride, nxt_stride = 4 * H;
+    for (int t = 0; t < n; ++t) {
+        const int b = slide0 + t;
+        const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f);
+        Mt.W2 = cur;
+        if (int rc = launch_forward(B, &Mt, ws, b, 1, use_bits, s, true, R, cur_stride)) return rc;
+        TileStepArgs ta = tile_step_args(B, &Mt, ws, labels, b, use_bits, k, nxt, 1, nullptr);
+        ta.n_runs = R->n_runs; ta.slide_stride = R->slide_stride;
+        ta.par_stride = R->par_stride; ta.img_stride = R->image_stride; ta.w2_stride = cur_stride; ta.w2out_stride = nxt_stride;
+        for (int r = 0; r < R->n_runs; ++r) {
+            const int sl = b + r * R->slide_stride;
+            ta.base_r[r] = B->row_off_host[sl];
+            int cap_, tb_;
+            tile_region(B, sl, &ta.slot0_r[r], &cap_, &tb_);
+            ta.cap_r[r] = cap_; ta.ntb_r[r] = tb_;
+        }
+        if (int rc = launch_tile_step(B, ta, R->n_runs, s)) return rc;
+        float* tmp = cur; cur = nxt; nxt = tmp;
+        const int64_t ts = cur_stride; cur_stride = nxt_stride; nxt_stride = ts;
+    }
+    if (cur != M->W2) {   // odd number of steps: every run's current W2 lives in the scratch buffer
+        if (hipMemcpy2DAsync(M->W2, sizeof(float) * (size_t)R->par_stride, cur, sizeof(float) * 4 * H, sizeof(float) * 4 * H,
+                             (size_t)R->n_runs, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            MOC_FAIL(MOC_ELAUNCH, "moc_train_steps_runs: copy-back of W2 failed");
     }
     return MOC_OK;
 }

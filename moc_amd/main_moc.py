@@ -513,6 +513,31 @@ def train(model, train_loader, optimizer, device, args):
         train.last = (batch, lab)    # keeps the buffers alive until the stream has drained; also for tests
 
 
+_run_sets = {}
+
+
+def train_runs(models, train_loaders, optimizers, device, args, generators=None):
+    """main_moc.py:378-410 for several independent runs at once -- what scripts/moc_train.sh:11-31 starts as one process per
+    (fold, shot): `train(models[r], train_loaders[r], optimizers[r], device, args)` for every r, stepped in lockstep by one
+    launch pair per meta-step (moc_amd.runs.TrainRuns; include/moc_hip.h moc_train_steps_runs).  Per run bit-identical to
+    `train` from the same mask stream; run r's masks come from `generators[r]` (a private CPU torch.Generator each; by
+    default seeded from the default generator on the first call).  The loaders are resident splits (ResidentBags) of equal
+    length.  -> the TrainRuns object (kept for the next pass: call again with the same lists)."""
+    from .runs import TrainRuns
+    key = (tuple(id(m) for m in models), tuple(id(o) for o in optimizers), tuple(id(l) for l in train_loaders),
+           args.topj, args.topk, tuple(sorted(args.discard_classifiers or ())), tuple(len(l) for l in train_loaders))
+    ent = _run_sets.get(key)
+    if ent is None:
+        if len(_run_sets) > 2:
+            _run_sets.clear()
+        ent = _run_sets[key] = (TrainRuns(models, optimizers, train_loaders, device, args, generators=generators),
+                                list(models), list(optimizers), list(train_loaders))
+    rs = ent[0]
+    rs.train_pass()
+    train_runs.last = rs
+    return rs
+
+
 def _binary_auc(pos: np.ndarray, score: np.ndarray) -> float:
     """Area under the ROC curve of `score` for the boolean labels `pos`: the Mann-Whitney statistic with
     mid-ranks for ties, which is what the trapezoid over sklearn's roc_curve thresholds adds up to."""

@@ -25,7 +25,8 @@ def _bench(*args, env=None, timeout=600):
 
 
 def test_one_gpu_line(gpu_device):
-    d = _bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2", "--steady-epochs", "10", "--packed-runs", "2")
+    d = _bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2", "--steady-epochs", "10", "--packed-runs", "2",
+               "--batched-runs", "2")
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "meta-steps/s"
     assert d["value"] > 5000 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1.0
     assert d["config"]["workload"].startswith("NSCLC 2-way 16-shot") and d["dtype"] == "f32" and d["vs_baseline"] is None
@@ -47,12 +48,15 @@ def test_one_gpu_line(gpu_device):
     # the mask draws a pass ahead); the margin covers clock and launch jitter on a 0.5-ms region
     assert d["value"] >= 0.6 * ss["value"], (d["value"], ss["value"])
     assert d["eval_slides_per_sec"] > 10000
+    br = d["batched_runs"]["runs_2"]                                  # two runs batched in one process (moc_amd.runs)
+    assert br["runs"] == 2 and br["value"] > d["value"] and 0.2 < br["score_pass"]["frac"] < 1.0
     pk = d["packed_runs"]
     assert pk["runs"] == 2 and pk["value"] > 5000 and "vs_one_run" in pk      # two independent runs on the one GPU, timed together
 
 
 def test_gpus_2_starts_its_own_ranks_and_reports_the_exact_sequential_mode(gpu_device):
     d = _bench("--gpus", "2", "--steps", "32", "--warmup", "32", "--no-eval", "--steady-epochs", "2", "--dp-exchange", "auto", "--dp-extra",
+               "--batched-runs", "0",
                env={"MOC_BENCH_ONE_DEVICE": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 100
     assert d["config"]["parallelism"].startswith("seq2: exact-sequential")
