@@ -177,6 +177,27 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Every 64-byte line of the first BYTES bytes of the kernel's argument segment, requested side by side and waited for
+// ONCE.  A latency-critical kernel with a few hundred bytes of arguments otherwise meets them one scalar-cache miss after
+// the other (each s_load of a new line in front of its first use: round 4 counted five serialised misses in front of the
+// step kernel's first vector load).  BYTES must not exceed the kernel's explicit arguments (nothing past them is read).
+template <size_t BYTES>
+__device__ __forceinline__ void moc_kernarg_touch() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(BYTES <= 1024, "moc_kernarg_touch: sixteen lines at most");
+    auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0, d6 = 0, d7 = 0, d8 = 0, d9 = 0, d10 = 0, d11 = 0, d12 = 0, d13 = 0, d14 = 0, d15 = 0;
+#define MOC_KA_LINE(i, off) if constexpr (BYTES > off) asm volatile("s_load_dword %0, %1, " #off : "=s"(d##i) : "s"(ka));
+    MOC_KA_LINE(0, 0x0) MOC_KA_LINE(1, 0x40) MOC_KA_LINE(2, 0x80) MOC_KA_LINE(3, 0xc0) MOC_KA_LINE(4, 0x100) MOC_KA_LINE(5, 0x140)
+    MOC_KA_LINE(6, 0x180) MOC_KA_LINE(7, 0x1c0) MOC_KA_LINE(8, 0x200) MOC_KA_LINE(9, 0x240) MOC_KA_LINE(10, 0x280) MOC_KA_LINE(11, 0x2c0)
+    MOC_KA_LINE(12, 0x300) MOC_KA_LINE(13, 0x340) MOC_KA_LINE(14, 0x380) MOC_KA_LINE(15, 0x3c0)
+#undef MOC_KA_LINE
+    // (the destinations stay allocated until everything has landed: they are inputs of the wait)
+    asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(d0), "s"(d1), "s"(d2), "s"(d3), "s"(d4), "s"(d5), "s"(d6), "s"(d7), "s"(d8), "s"(d9),
+                 "s"(d10), "s"(d11), "s"(d12), "s"(d13), "s"(d14), "s"(d15) : "memory");
+#endif
+}
+
 // ---- diagnostic build only (-DMOC_STAMPS, make stamps): constant-clock (100 MHz) time stamps of
 // kernel phases, written by thread 0 of workgroup (0,0) to a global array that nothing else reads.
 #ifdef MOC_STAMPS

@@ -267,13 +267,21 @@ __device__ __forceinline__ void fwd_fold_quarter(f32x4_t& tot, f32x4_t& acc, boo
 }
 
 // grid (ceil(S_bound/16), n): one workgroup = 16 selected rows, wave w = hidden units 16w..16w+15.
-template <bool BF16, bool F16 = false>
+// TILES: the tile-record variant (training step over tile records, batched runs); without it the kernel is the round-3 code --
+// the extra live values cost this 256-register kernel 4.6 us at thirty classes when they were unconditional
+template <bool BF16, bool F16 = false, bool TILES = false>
 __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
     __shared__ __attribute__((aligned(16))) uint4 xt[16 * 64];     // 16 rows x 1 KiB, chunk-swizzled
     __shared__ float Hs[16][H + 1];
     __shared__ float Gs[16][4];
     __shared__ float W2s[4 * H];
-    const FwdRun fr = fwd_run_setup(a);
+    FwdRun fr;
+    if constexpr (TILES) fr = fwd_run_setup(a);
+    else {
+        fr.b = a.slide0 + blockIdx.y;
+        fr.base = a.base_host >= 0 ? a.base_host : a.row_off[fr.b];
+        fr.W1img = a.W1img; fr.W2 = a.W2; fr.b1 = a.b1; fr.b2 = a.b2; fr.tile_slot0 = 0; fr.tile_cap = 0;
+    }
     const int b = fr.b;
     const int64_t base = fr.base;
     const int S = a.n_sel[b];
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
     const float bias = fr.b1[wave * 16 + (lane & 15)];
     const float b2_pre = fr.b2[threadIdx.x & 3];
     int64_t rid_e = 0;                                               // tile records: the bag row of this thread's (row, class)
-    if (a.tile_on) rid_e = a.sel_row[base + min(row0 + (int)(threadIdx.x & 15), S - 1)];
+    if constexpr (TILES) { if (a.tile_on) rid_e = a.sel_row[base + min(row0 + (int)(threadIdx.x & 15), S - 1)]; }
     // The 16 x D tile of x goes through LDS once per workgroup: wave w fetches rows 4w..4w+3 with
     // whole-row contiguous loads (UB bytes per row per unit) and stores 16-B chunk c of row r at
     // chunk c ^ (r & 15), so that the A-fragment reads (lane l: row l&15, chunk 4*kk + (l>>4)) hit
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
         if (a.use_bits & 8u) v = moc_fadd(v, moc_fmul(Gs[r][3], s3));
         a.mixed[(int64_t)c * a.stride + base + row0 + r] = v;
     }
-    if (a.tile_on && threadIdx.x < 16 * C) {                         // (C <= 16 here: one element per thread)
+    if (TILES && a.tile_on && threadIdx.x < 16 * C) {                // (C <= 16 here: one element per thread)
         const int r = threadIdx.x & 15, c = threadIdx.x >> 4;
         const bool ok = row0 + r < S;
         float v = 0.f;
@@ -1847,21 +1855,7 @@ struct TileStepArgs {
 template <int VQ>
 __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    {   // every cache line of the arguments, requested side by side, one wait
-        static_assert(sizeof(TileStepArgs) <= 1024, "TileStepArgs outgrew the lines touched here");
-#if defined(__HIP_DEVICE_COMPILE__)
-        auto ka = __builtin_amdgcn_kernarg_segment_ptr();
-        unsigned k0, k1, k2, k3, k4, k5, k6, k7;
-        asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\t"
-                     "s_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\t"
-                     "s_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\t"
-                     "s_load_dword %0, %8, 0x200\n\ts_load_dword %1, %8, 0x240\n\ts_load_dword %2, %8, 0x280\n\t"
-                     "s_load_dword %3, %8, 0x2c0\n\ts_load_dword %4, %8, 0x300\n\ts_load_dword %5, %8, 0x340\n\t"
-                     "s_load_dword %6, %8, 0x380\n\ts_load_dword %7, %8, 0x3c0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3), "=&s"(k4), "=&s"(k5), "=&s"(k6), "=&s"(k7)
-                     : "s"(ka) : "memory");
-#endif
-    }
+    moc_kernarg_touch<sizeof(TileStepArgs)>();           // every cache line of the arguments, requested side by side, one wait
     // batched runs: this workgroup's run -- its slide, its region of the records, the offsets of its tensors (the argument
     // block itself is not modified and its arrays are read through kernarg_at: either would send all of it to scratch)
     int b = a.slide0;
@@ -2293,6 +2287,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     const int b = a.slide0, C = a.C, K = a.K, D = a.D;
     const int wg = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int DS = D / 16, d_lo = wg * DS;               // this workgroup's columns of W1
+    moc_kernarg_touch<sizeof(FusedArgs)>();
     MOC_STAMP(40);
     const int esz = a.xdt == MOC_F32 ? 4 : 2;
     const int PMAX = C * K;
@@ -2881,7 +2876,7 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
         static const int fwd4_env = getenv("MOC_RUNS_FWD4") ? atoi(getenv("MOC_RUNS_FWD4")) : -1;
         const bool four = fwd4_env >= 0 ? fwd4_env != 0 : (int64_t)grid.x * grid.y > 512;
         if (B->dtype == MOC_F32 && four && B->C <= 16) {
-            meta_forward_kernel<false><<<grid, 256, 0, s>>>(a);
+            meta_forward_kernel<false, false, true><<<grid, 256, 0, s>>>(a);
             MOC_CHECK_LAUNCH("moc_meta_forward(runs, four waves)");
             return MOC_OK;
         }
@@ -2900,8 +2895,8 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
                 case 3: meta_forward_ksplit_kernel<3, false><<<grid, 1024, lds, s>>>(a); break;
                 default: meta_forward_ksplit_kernel<4, false><<<grid, 1024, lds, s>>>(a); break;
             }
-        } else if (B->dtype == MOC_F16) meta_forward_kernel<true, true><<<grid, 256, 0, s>>>(a);
-        else meta_forward_kernel<true><<<grid, 256, 0, s>>>(a);
+        } else if (B->dtype == MOC_F16) meta_forward_kernel<true, true, true><<<grid, 256, 0, s>>>(a);
+        else meta_forward_kernel<true, false, true><<<grid, 256, 0, s>>>(a);
         MOC_CHECK_LAUNCH("moc_meta_forward(runs)");
         return MOC_OK;
     }
@@ -2956,7 +2951,11 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
         MOC_CHECK_LAUNCH("moc_meta_forward(ksplit)");
         return MOC_OK;
     }
-    if (B->dtype == MOC_F16) meta_forward_kernel<true, true><<<grid, 256, 0, s>>>(a);
+    if (a.tile_on) {
+        if (B->dtype == MOC_F16) meta_forward_kernel<true, true, true><<<grid, 256, 0, s>>>(a);
+        else if (B->dtype == MOC_BF16) meta_forward_kernel<true, false, true><<<grid, 256, 0, s>>>(a);
+        else meta_forward_kernel<false, false, true><<<grid, 256, 0, s>>>(a);
+    } else if (B->dtype == MOC_F16) meta_forward_kernel<true, true><<<grid, 256, 0, s>>>(a);
     else if (B->dtype == MOC_BF16) meta_forward_kernel<true><<<grid, 256, 0, s>>>(a);
     else meta_forward_kernel<false><<<grid, 256, 0, s>>>(a);
     MOC_CHECK_LAUNCH("moc_meta_forward");
