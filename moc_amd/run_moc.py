@@ -6,6 +6,7 @@ around the GPU callables of moc_amd.main_moc.
     python -m moc_amd.run_moc --summary --summary_dir results/moc_train/nsclc
     python -m moc_amd.run_moc --synthetic 24 --shot 4 --disable_tqdm        # no data needed
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m moc_amd.run_moc ...   # 8 GPUs
+    python -m moc_amd.run_moc --folds 0,1,2,3,4 --shot 16 --seed 1 ...      # five folds in ONE process, stepped in lockstep
 
 Same flags and defaults as the reference, same result files (`zs_results_*`, `best_results_*`,
 `ablation_results_*`, `best_model_*.pt`, `summary_*.csv`) with the same keys.  Differences, all
@@ -74,6 +75,11 @@ def get_args(argv=None):
     p.add_argument("--epochs", type=int, default=25, help="main_moc.py:611 hard-codes 25")
     p.add_argument("--synthetic", type=int, default=0, help="run on N generated slides per split instead of files")
     p.add_argument("--seed", type=int, default=None, help="torch.manual_seed before building the meta-learner")
+    p.add_argument("--folds", type=str, default="",
+                   help="comma-separated folds: train them ALL in this process, stepped in lockstep (moc_amd.main_moc.train_runs) -- "
+                        "what scripts/moc_train.sh starts as one process per fold.  Every fold's numbers and files are those of "
+                        "`--fold F` alone (with --seed: bit for bit).  Under a launcher the folds are dealt to the ranks, no "
+                        "communication")
     return p.parse_args(argv)
 
 
@@ -156,7 +162,9 @@ def prepare(args, device):
         M.set_classifier_bank(W.to(device), We.to(device))
         dt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.bag_dtype, torch.float32)
         loaders = []
-        for s, (base, n, rep) in enumerate(((100, args.shot * C, args.shot * C), (5000, args.synthetic, None), (9000, args.synthetic, None))):
+        fo = 17 * int(getattr(args, "fold", 0))          # (every fold its own generated slides; fold 0: the fixtures' slides)
+        for s, (base, n, rep) in enumerate(((100 + fo, args.shot * C, args.shot * C), (5000 + fo, args.synthetic, None),
+                                            (9000 + fo, args.synthetic, None))):
             sizes = synth.bag_sizes(base, n, 3000, fixed=False, lo=500, hi=8000)
             if world > 1:                    # every rank generates only the slides of its block (seeds are per slide)
                 blocks = mdist.block_lists(n, world)
@@ -286,6 +294,98 @@ def main(args, model, optimizer, train_loader, val_loader, test_loader, device):
     return results
 
 
+def main_runs(args_list, models, optimizers, loaders_list, device, generators=None):
+    """main() (main_moc.py:586-644) for several runs at once: the zero-shot evaluations and the per-epoch evaluations run
+    per run, the training passes of all runs in lockstep (moc_amd.main_moc.train_runs).  `args_list[r]` carries run r's
+    fold / shot / result_dir; loaders_list[r] = (train, val, test) resident splits.  Every run prints, saves and returns what
+    main() would for it alone.  -> list of result dicts."""
+    R = len(models)
+    a0 = args_list[0]
+    assert a0.ablation_study == "none", "main_runs: the ablation study trains nothing -- run it per fold"
+    st = []
+    for r in range(R):
+        a = args_list[r]
+        os.makedirs(a.result_dir, exist_ok=True)
+        tr, va, te = loaders_list[r]
+        zs = (-1, -1, -1)
+        if a.check_zeroshot:
+            zs = (M.zs_evaluation(tr, device, a), M.zs_evaluation(va, device, a), M.zs_evaluation(te, device, a))
+            print(f"[fold {a.fold}] Zero-shot Train: {zs[0]}, Val: {zs[1]}, Test: {zs[2]}")
+            with open(os.path.join(a.result_dir, f"zs_results_shot_{a.shot}_fold_{a.fold}.json"), "w") as f:
+                json.dump({"zs_train": zs[0], "zs_val": zs[1], "zs_test": zs[2]}, f, indent=4)
+        st.append(dict(zs=zs, best_val=0, test_at_best_val=0, test_acc_at_best_val=0, best_epoch=0,
+                       model_path=os.path.join(a.result_dir, f"best_model_shot_{a.shot}_fold_{a.fold}.pt")))
+    trains = [ls[0] for ls in loaders_list]
+    for epoch in range(getattr(a0, "epochs", 25)):
+        print("Epoch: ", epoch)
+        M.train_runs(models, trains, optimizers, device, a0, generators=generators)
+        for r in range(R):
+            a, s_ = args_list[r], st[r]
+            tr, va, te = loaders_list[r]
+            train_eval = M.evaluation(models[r], tr, device, a)
+            val_eval = M.evaluation(models[r], va, device, a)
+            if val_eval["auc"] > s_["best_val"]:
+                test_eval = M.evaluation(models[r], te, device, a)
+                print(f"[fold {a.fold}] Epoch: {epoch}, Train: {train_eval}, Val: {val_eval}, Test: {test_eval}")
+                s_.update(best_val=val_eval["auc"], test_at_best_val=test_eval["auc"], test_acc_at_best_val=test_eval["acc"], best_epoch=epoch)
+                torch.save(models[r].state_dict(), s_["model_path"])
+            else:
+                print(f"[fold {a.fold}] Epoch: {epoch}, Train: {train_eval}, Val: {val_eval}")
+    out = []
+    for r in range(R):
+        a, s_ = args_list[r], st[r]
+        print(f"[fold {a.fold}] Best Val: {s_['best_val']}, Test at Best Val: {s_['test_at_best_val']}, Test acc: {s_['test_acc_at_best_val']}, "
+              f"Best Epoch: {s_['best_epoch']}")
+        res = {"zero_shot_train": s_["zs"][0], "zero_shot_val": s_["zs"][1], "zero_shot_test": s_["zs"][2],
+               "best_val": s_["best_val"], "test_at_best_val": s_["test_at_best_val"], "test_acc_at_best_val": s_["test_acc_at_best_val"],
+               "best_epoch": s_["best_epoch"], "best_model_path": s_["model_path"]}
+        with open(os.path.join(a.result_dir, f"best_results_shot_{a.shot}_fold_{a.fold}.json"), "w") as f:
+            json.dump(res, f, indent=4)
+        out.append(res)
+    print("\nEnd training.")
+    return out
+
+
+def folds_of_rank(spec: str, rank: int, world: int):
+    """The folds of `--folds a,b,...` this rank trains: dealt round-robin, every fold exactly once over the job (runs x
+    GPUs: whole runs shard over the ranks, nothing is exchanged -- SURVEY.md section 8e, the reference's own launcher)."""
+    folds = [int(v) for v in spec.split(",") if v.strip() != ""]
+    assert len(set(folds)) == len(folds), "--folds: a fold named twice"
+    return folds[rank::world]
+
+
+def cli_folds(args):
+    """`--folds a,b,...`: those folds in this process (under a launcher: this rank's share of them, nothing exchanged)."""
+    import copy
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    folds = folds_of_rank(args.folds, rank, world)
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else torch.cuda.current_device())
+    torch.cuda.set_device(device)
+    if not folds:
+        print(f"rank {rank}: no fold to train")
+        return []
+    assert not args.loader_seed_draw, "--folds: the runs draw their masks from private generators (no DataLoader base-seed draw)"
+    args_list, models, optimizers, loaders_list, gens = [], [], [], [], []
+    for fold in folds:
+        a = copy.copy(args)
+        a.fold = fold
+        loaders = prepare(a, device)
+        assert all(isinstance(ld, M.ResidentBags) for ld in loaders), "--folds needs resident splits (--resident 1)"
+        # exactly what `--fold F` alone does with the default generator: seed, build the meta-learner, and the masks follow
+        # from wherever that leaves the stream -- here in a generator of the run's own
+        if args.seed is not None:
+            torch.manual_seed(args.seed)
+        model = M.senet(512, 4).to(device)
+        g = torch.Generator()
+        g.set_state(torch.get_rng_state())
+        args_list.append(a)
+        models.append(model)
+        optimizers.append(torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4))
+        loaders_list.append(loaders)
+        gens.append(g)
+    return main_runs(args_list, models, optimizers, loaders_list, device, generators=gens)
+
+
 def cli(argv=None):
     args = get_args(argv)
     if args.summary:
@@ -293,6 +393,8 @@ def cli(argv=None):
         return None
     if not torch.cuda.is_available():
         raise RuntimeError("moc_amd needs a GPU: there is no CPU fallback")
+    if args.folds:
+        return cli_folds(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:                                   # one process per GPU under a launcher (torch.distributed.run)
         import torch.distributed as dist

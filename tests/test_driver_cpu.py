@@ -141,3 +141,14 @@ def test_direct_auc_equals_sklearn():
         mine, theirs = run(_auc, y, p), run(roc_auc_score, y, p, **kw)
         assert mine[0] == theirs[0]
         assert mine[1] == theirs[1] or (isinstance(mine[1], float) and np.isnan(mine[1]) and np.isnan(theirs[1]))
+
+
+def test_folds_are_dealt_to_the_ranks_exactly_once():
+    from moc_amd.run_moc import folds_of_rank
+    for world in (1, 2, 3, 8):
+        got = [folds_of_rank("0,1,2,3,4", r, world) for r in range(world)]
+        assert sorted(f for part in got for f in part) == [0, 1, 2, 3, 4]
+        assert max(len(p) for p in got) - min(len(p) for p in got) <= 1
+    assert folds_of_rank("3, 1", 0, 1) == [3, 1]
+    with pytest.raises(AssertionError):
+        folds_of_rank("1,1", 0, 1)

@@ -101,3 +101,23 @@ def test_runs_must_agree_on_what_they_share(dev):
     opts[1] = torch.optim.Adam(models[1].parameters(), lr=1e-3)
     with pytest.raises(AssertionError, match="private CPU generator"):
         M.train_runs(models, splits, opts, dev, H.make_args(2, 100, 10), generators=[torch.default_generator, torch.Generator()])
+
+
+def test_folds_in_one_process_reproduce_each_fold_alone(dev, tmp_path):
+    """`run_moc --folds 0,1,2`: the reference's launcher (scripts/moc_train.sh:11-31) in one process.  Every fold's result
+    file holds the numbers of `--fold F` alone, its best checkpoint the same bits."""
+    import json, os
+    from moc_amd import run_moc
+    common = ["--synthetic", "6", "--shot", "2", "--seed", "3", "--epochs", "4", "--topj", "100", "--topk", "10", "--disable_tqdm"]
+    together = run_moc.cli(common + ["--folds", "0,1,2", "--result_dir", str(tmp_path / "together")])
+    assert len(together) == 3
+    for fold in range(3):
+        alone = run_moc.cli(common + ["--fold", str(fold), "--result_dir", str(tmp_path / "alone")])
+        a = json.load(open(tmp_path / "alone" / f"best_results_shot_2_fold_{fold}.json"))
+        b = json.load(open(tmp_path / "together" / f"best_results_shot_2_fold_{fold}.json"))
+        for k in ("zero_shot_train", "zero_shot_val", "zero_shot_test", "best_val", "test_at_best_val", "test_acc_at_best_val", "best_epoch"):
+            assert a[k] == b[k] == alone[k], (fold, k, a[k], b[k])
+        sa = torch.load(tmp_path / "alone" / f"best_model_shot_2_fold_{fold}.pt", map_location="cpu")
+        sb = torch.load(tmp_path / "together" / f"best_model_shot_2_fold_{fold}.pt", map_location="cpu")
+        assert sa.keys() == sb.keys() and all(torch.equal(sa[k], sb[k]) for k in sa)
+        assert os.path.exists(tmp_path / "together" / f"zs_results_shot_2_fold_{fold}.json")
