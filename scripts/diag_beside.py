@@ -64,6 +64,41 @@ if len(sys.argv) > 1 and sys.argv[1] == "cont":
         torch.cuda.synchronize()
         print(f"{label}: steps {e0.elapsed_time(e1) * 1e3 / 320:.2f} us/step while score passes run beside at {s0.elapsed_time(s1) * 1e3 / 60:.1f} us each")
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "split":
+    # the score pass IN LINE on the main stream at the pass boundary (whole chip, static walk, full speed), the rest of
+    # phase A on the side stream beside the steps -- against the whole phase A on the side stream (what the loop does)
+    other.reserve_cus(0)
+    def one_pass_split():
+        engine.train_steps(batch, meta, lab, 0, 32, 15)
+        check(lib().moc_scores(C.byref(other.c), ptr(bank.image), engine._stream()), "moc_scores")     # main stream, after the steps
+        ev = torch.cuda.Event(); ev.record(engine.stream_obj())
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            other.select(); other.gather_candidates()
+            check(lib().moc_mask_compact(C.byref(other.c), engine._stream()), "mc")                   # (the NEXT pass's flags)
+    def one_pass_side(reserve):
+        other.reserve_cus(reserve)
+        def f():
+            engine.train_steps(batch, meta, lab, 0, 32, 15)
+            with torch.cuda.stream(side):
+                other.phase_a(bank)
+        return f
+    for label, fn in (("steps only", lambda: engine.train_steps(batch, meta, lab, 0, 32, 15)), ("score in line + rest beside", one_pass_split),
+                      ("phase A beside, 64 CUs reserved", one_pass_side(64)), ("phase A beside, whole chip", one_pass_side(0)),
+                      ("score in line + rest beside", one_pass_split)):
+        if label.startswith("score"):
+            other.reserve_cus(0)
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(40):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"{label:40s} {e0.elapsed_time(e1) * 1e3 / 40:7.1f} us per pass ({40 * 32 / (e0.elapsed_time(e1) * 1e-3):7.0f} steps/s)")
+    sys.exit(0)
 run("nothing beside", None)
 if len(sys.argv) > 1 and sys.argv[1] == "hold":
     for nwg, hold in ((1, 300), (8, 100), (8, 300), (8, 1000), (64, 300), (256, 300), (2048, 300), (2048, 100), (16384, 300)):
