@@ -326,8 +326,22 @@ class SlideBatch:
             return
         # same four launches, with events around the score pass
         check(lib().moc_mask_compact(C.byref(self.c), _stream()), "moc_mask_compact")
-        e0, e1 = timed_scores(self, bank)
-        SCORE_EVENTS.append((e0, e1, self.kept_rows_host * self.D * self.X.element_size()))
+        self.phase_a_tail(bank)
+
+    def phase_a_head(self, bank: Bank):
+        """The first launch of phase A alone -- the kept-row lists from the keep flags (read over PCIe when they are host
+        flags) -- for a caller that runs it ahead of the rest (moc_amd.runs)."""
+        assert bank.D == self.D and bank.C == self.C and bank.Ce == self.Ce and bank.dtype == self.X.dtype
+        self._layout(COMPACT_STATS and self.Ce > 16)
+        check(lib().moc_mask_compact(C.byref(self.c), _stream()), "moc_mask_compact")
+
+    def phase_a_tail(self, bank: Bank):
+        """... and the rest: score pass (timed when bench.py collects SCORE_EVENTS), selection, union, candidates."""
+        if SCORE_EVENTS is None:
+            check(lib().moc_scores(C.byref(self.c), ptr(bank.image), _stream()), "moc_scores")
+        else:
+            e0, e1 = timed_scores(self, bank)
+            SCORE_EVENTS.append((e0, e1, self.kept_rows_host * self.D * self.X.element_size()))
         self.select()
         self.gather_candidates()
 

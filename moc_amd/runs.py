@@ -171,8 +171,9 @@ class TrainRuns:
         self.flag_busy[0] = None
         return 0
 
-    def _phase_a(self, turn):
-        """Masks + phase A of the next pass into work-array set `turn`, on the CURRENT stream."""
+    def _phase_a(self, turn, head_only=False):
+        """Masks + phase A of the next pass into work-array set `turn`, on the CURRENT stream (head_only: the flags and the
+        kept-row lists only; `_phase_a_tail` does the rest)."""
         i = self._free_flags()
         kept, max_kept = self._draw(self.flags[i])
         batch = self.batches[turn]
@@ -183,7 +184,10 @@ class TrainRuns:
             batch.c.max_rows = max(1, max_kept)
         else:
             batch.use_host_mask(self.flags[i], kept, max_kept)
-        batch.phase_a(self.bank)
+        if head_only:
+            batch.phase_a_head(self.bank)
+        else:
+            batch.phase_a(self.bank)
         ev = torch.cuda.Event()
         ev.record(engine.stream_obj())
         self.flag_busy[i] = ev
@@ -199,6 +203,8 @@ class TrainRuns:
         if ahead is not None:
             ahead["done"].wait(engine.stream_obj())
             self.turn = ahead["turn"]
+            if ahead.get("head_only"):                        # its kept-row lists exist: score pass, selection, candidates now
+                self.batches[self.turn].phase_a_tail(self.bank)
         else:
             self.turn = 1 - self.turn
             self._phase_a(self.turn)
@@ -238,15 +244,15 @@ class TrainRuns:
         mark = torch.cuda.Event()
         mark.record(engine.stream_obj())
         self.steps_done[self.turn] = mark
-        if not self.lookahead:
-            return
-        # phase A of the NEXT pass, on the side stream, into the other set (free once the pass before this one has run)
+        # The NEXT pass, on the side stream, into the other set (free once the pass before this one has run): its flags and
+        # kept-row lists -- the compaction kernel reads the flags over PCIe, 77 us at eight runs, which costs the steps
+        # nothing -- or (MOC_RUNS_LOOKAHEAD=1) all of its phase A (measured slower: the steps crawl under a score pass)
         other = 1 - self.turn
         if self.steps_done[other] is not None:
             self.steps_done[other].synchronize()
         with torch.cuda.stream(self.side):
-            done = self._phase_a(other)
-        self.ahead = {"turn": other, "done": done}
+            done = self._phase_a(other, head_only=not self.lookahead)
+        self.ahead = {"turn": other, "done": done, "head_only": not self.lookahead}
 
     def losses(self):
         """[R, n] losses of the last pass (device)."""
