@@ -110,6 +110,7 @@ def parse():
     ap.add_argument("--packed-runs", type=int, default=4,
                     help="N = 1: also measure this many independent training runs side by side on the ONE GPU (separate processes, "
                          "as scripts/moc_train.sh of the reference packs five folds onto a GPU); 0 = skip")
+    ap.add_argument("--no-cached-extra", action="store_true", help="skip the cached_scores extra block")
     ap.add_argument("--batched-runs", default="8,16",
                     help="N = 1: also time R independent runs batched in THIS process (moc_amd.runs), for every R of this "
                          "comma-separated list (the `batched_runs` block; '' or 0: skip)")
@@ -570,6 +571,36 @@ def main():
         except Exception as e:  # noqa: BLE001 -- an extra block must not cost the line its `value`
             half_block = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    # ---- opt-in: the per-row statistics kept from ONE score pass (ResidentBags(cache_scores=True)): no score pass per epoch.
+    # NOT `value` -- its score pass reads the bags every pass, as the reference recomputes them -- an extra block
+    cached_block = None
+    if world == 1 and main_mode == "single" and not a.no_cached_extra and not a.replicas_only:
+        try:
+            ev_keep, engine.SCORE_EVENTS = engine.SCORE_EVENTS, None
+            keep_env = os.environ.get("MOC_CACHE_SCORES")
+            os.environ["MOC_CACHE_SCORES"] = "1"
+            try:
+                rc_ = measure("single", a.steps, a.warmup, 0 if a.no_steady else min(200, a.steady_epochs))
+                cached_runs8 = run_batched(8) if a.batched_runs not in ("", "0") else None
+            finally:
+                if keep_env is None:
+                    os.environ.pop("MOC_CACHE_SCORES", None)
+                else:
+                    os.environ["MOC_CACHE_SCORES"] = keep_env
+            engine.SCORE_EVENTS = ev_keep
+            cached_block = {"value": round(rc_["value"], 1), "unit": "meta-steps/s", "steps": a.steps, "warmup": a.warmup,
+                            "steady_state": rc_["steady"] and rc_["steady"]["value"], "batched_runs_8": cached_runs8,
+                            "note": "opt-in (ResidentBags(cache_scores=True), run_moc --cache_scores 1): the classifier bank is frozen, so a "
+                                    "row's statistics are the same on every visit; they are kept from ONE unmasked score pass (28 B per "
+                                    "2-KiB row) and a train pass copies its kept rows' statistics instead of reading the bags again -- "
+                                    "bit-identical training (tests: test_cached_statistics_give_the_score_pass_bits).  Not `value`: "
+                                    "there the score pass reads the bags every pass, as the reference recomputes feat @ W "
+                                    "(main_moc.py:336-337)"}
+            rc_["loop"] = rc_["res"] = rc_["model"] = None
+            del rc_
+        except Exception as e:  # noqa: BLE001 -- an extra block must not cost the line its `value`
+            cached_block = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     # ---- the modes that are not `value`, from shorter runs of this process, as extra keys (N > 1 only)
     extras = {}
     if world > 1 and (main_mode != "seq" or a.dp_extra):
@@ -660,9 +691,8 @@ def main():
     # ---- the same, inside ONE process: R independent runs stepped in lockstep by one launch pair per meta-step
     # (moc_amd.runs / moc_train_steps_runs).  `value` above stays the rate of ONE run.
     batched = None
-    if world == 1 and a.batched_runs not in ("", "0") and not a.replicas_only and not (a.force_dp or a.force_seq):
-        batched = {}
-        for R_ in [int(v) for v in a.batched_runs.split(",") if int(v) > 1]:
+
+    def run_batched(R_):
             try:
                 torch.cuda.synchronize()
                 models_, opts_, splits_ = [], [], []
@@ -687,18 +717,26 @@ def main():
                 ev_, engine.SCORE_EVENTS = engine.SCORE_EVENTS, None
                 sms = sum(s_.elapsed_time(e_) for s_, e_, _ in ev_)
                 sby = sum(b_ for _, _, b_ in ev_)
-                batched[f"runs_{R_}"] = {
+                blk = {
                     "runs": R_, "value": round(R_ * a.slides * E_ / bdt, 1), "unit": "meta-steps/s (all runs together, ONE GPU, ONE process)",
-                    "vs_one_run": round(R_ * a.slides * E_ / bdt / value, 2), "passes": E_, "us_per_pass": round(bdt / E_ * 1e6, 1),
-                    "score_pass": {"achieved": round(sby / (sms * 1e-3) / 1e9, 1), "frac": round(sby / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                   "unit": "GB/s", "avg_launch_us": round(sms / max(1, len(ev_)) * 1e3, 1),
-                                   "note": "one launch over the R x %d slides of a pass, whole chip, nothing beside it" % a.slides}}
+                    "vs_one_run": round(R_ * a.slides * E_ / bdt / value, 2), "passes": E_, "us_per_pass": round(bdt / E_ * 1e6, 1)}
+                if sms > 0:
+                    blk["score_pass"] = {"achieved": round(sby / (sms * 1e-3) / 1e9, 1), "frac": round(sby / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "unit": "GB/s", "avg_launch_us": round(sms / max(1, len(ev_)) * 1e3, 1),
+                                         "note": "one launch over the R x %d slides of a pass, whole chip, nothing beside it" % a.slides}
                 del models_, opts_, splits_
                 M._run_sets.clear()
                 torch.cuda.empty_cache()
+                return blk
             except Exception as e:  # noqa: BLE001 -- an extra block must not cost the line its `value`
                 engine.SCORE_EVENTS = None
-                batched[f"runs_{R_}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                M._run_sets.clear()
+                return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    if world == 1 and a.batched_runs not in ("", "0") and not a.replicas_only and not (a.force_dp or a.force_seq):
+        batched = {}
+        for R_ in [int(v) for v in a.batched_runs.split(",") if int(v) > 1]:
+            batched[f"runs_{R_}"] = run_batched(R_)
         batched["note"] = ("R independent training runs (own slides, parameters, Adam state, mask stream) in ONE process: one forward "
                            "and one step launch per meta-step serve all of them (grid.y / grid.z = run), phase A over all R x n "
                            "slides in one pass.  Per run bit-identical to main_moc.train (tests/test_gpu_runs.py).  The reference's "
@@ -803,6 +841,8 @@ def main():
             out["packed_runs"] = packed
         if batched:
             out["batched_runs"] = batched
+        if cached_block:
+            out["cached_scores"] = cached_block
         if extras:
             out["minibatch_dp" if main_mode == "seq" else "other_modes"] = dict(
                 extras, note="synchronous minibatch data parallelism: one Adam step per N slides -- an opt-in extension "

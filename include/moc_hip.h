@@ -212,6 +212,13 @@ int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t stream);
  * reports it, whatever else the GPU is running.  bench.py's `roofline` uses it. */
 int moc_scores_timed(const moc_batch_t* B, const void* bank, moc_stream_t stream, void* start_event, void* stop_event);
 
+/* a2 from a cache (round 4, opt-in): the statistics of a row depend only on the row and the frozen bank, so a resident
+ * split can keep the statistics of ALL its rows (`stats_all` [rows of stats, all_rows], laid out like `stats` and indexed
+ * by the row's position in B->X: the output of an UNMASKED moc_scores over the split with the same B->flags layout) and a
+ * pass then copies the kept rows' statistics into slot order instead of reading the bags again (main_moc.py:336-337 is
+ * recomputed per visit in the reference; the bits are the same).  Needs moc_mask_compact's lists for a masked batch. */
+int moc_scores_from_cache(const moc_batch_t* B, const float* stats_all, int64_t all_rows, moc_stream_t stream);
+
 /* The same statistics from an already computed logits matrix (device [N, Ct] row-major,
  * first C columns foreground): stats_out is [2C+3, N].  For callers that hold logits, not
  * bags (index_*_classifier / *_pooling, utils/patch_selection_classifier*.py).  With C == 1

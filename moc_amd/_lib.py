@@ -73,6 +73,7 @@ SIGNATURES = {
     "moc_mask_compact": (C.c_int, [_BP, _p]),
     "moc_scores": (C.c_int, [_BP, _p, _p]),
     "moc_scores_timed": (C.c_int, [_BP, _p, _p, _p, _p]),
+    "moc_scores_from_cache": (C.c_int, [_BP, _p, C.c_int64, _p]),
     "moc_row_stats": (C.c_int, [_p, C.c_int64, C.c_int, C.c_int, _p, _p]),
     "moc_select": (C.c_int, [_BP, _p]),
     "moc_gather_candidates": (C.c_int, [_BP, _p, _p]),

@@ -1132,6 +1132,29 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* logits, int
     s[(int64_t)(2 * C + 2) * N] = bmax;
 }
 
+// ---- the score pass from a cache (round 4, opt-in) ---------------------------------------------------------------------
+// The per-row statistics of a bag depend on nothing but the row and the frozen classifier bank -- not on the epoch, not
+// on the mask, not on which other rows share its MFMA tile (every output element is one row's dot products, accumulated in
+// a fixed order) -- yet the reference (and moc_scores) recompute them on every visit (main_moc.py:336-337).  With 288 GB of
+// HBM the statistics of EVERY row of a resident split are 28 bytes per 2-KiB row: computed once by an unmasked moc_scores,
+// kept, and a train pass then only copies the kept rows' statistics into slot order -- the same bits the score pass would
+// write, without reading the bags.  NOT what bench.py's `value` measures (its score pass reads the bags every pass).
+// grid (ceil(max_rows / 256), n_slides)
+__global__ __launch_bounds__(256) void stats_from_cache_kernel(const float* all, int64_t all_stride, float* stats, int64_t stride,
+                                                               uint8_t* sel_flag, const int64_t* row_off, const int64_t* x_off,
+                                                               const int32_t* kept, const int32_t* n_kept, int NS) {
+    const int b = blockIdx.y;
+    const int64_t base = row_off[b];
+    const int n = (int)(row_off[b + 1] - base);
+    const int nk = kept ? n_kept[b] : n;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= nk) return;
+    const int r = kept ? kept[base + slot] : slot;
+    const int64_t xr = (x_off ? x_off[b] : base) + r;
+    for (int c = 0; c < NS; ++c) stats[(int64_t)c * stride + base + slot] = all[(int64_t)c * all_stride + xr];
+    sel_flag[base + slot] = 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ host entry points
@@ -1405,6 +1428,18 @@ extern "C" int moc_scores(const moc_batch_t* B, const void* bank, moc_stream_t s
 extern "C" int moc_scores_timed(const moc_batch_t* B, const void* bank, moc_stream_t stream, void* start_event, void* stop_event) {
     MOC_REQUIRE(start_event && stop_event, "moc_scores_timed: null event");
     return scores_impl(B, bank, stream, (hipEvent_t)start_event, (hipEvent_t)stop_event);
+}
+
+extern "C" int moc_scores_from_cache(const moc_batch_t* B, const float* stats_all, int64_t all_rows, moc_stream_t stream) {
+    if (int rc = moc_check_batch(B, "moc_scores_from_cache")) return rc;
+    MOC_REQUIRE(stats_all && B->stats && B->sel_flag && all_rows > 0, "moc_scores_from_cache: null stats / cache");
+    MOC_REQUIRE(!B->mask || (B->kept && B->n_kept), "moc_scores_from_cache: a masked batch needs its kept-row lists (moc_mask_compact)");
+    const int NS = (B->flags & MOC_STATS_COMPACT) ? B->C + 5 : 2 * B->C + 3;
+    dim3 grid(moc_cdiv(B->max_rows, 256), B->n_slides);
+    stats_from_cache_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(stats_all, all_rows, B->stats, B->total_rows, B->sel_flag, B->row_off,
+                                                                   B->x_off, B->mask ? B->kept : nullptr, B->n_kept, NS);
+    MOC_CHECK_LAUNCH("moc_scores_from_cache");
+    return MOC_OK;
 }
 
 extern "C" int moc_row_stats(const float* logits, int64_t N, int Ct, int C, float* stats, moc_stream_t stream) {

@@ -267,6 +267,7 @@ class SlideBatch:
         self.ticket = None
         self.cu_reserved = None
         self._ws = None
+        self.stats_cache = None          # (statistics of every row of X, layout flag): phase A copies instead of reading the bags
 
     def reserve_cus(self, n: int | None = None, ticket: bool | None = None):
         """This batch's score passes stay off `n` compute units (default MOC_RESERVE_CUS) and hand their tiles out by
@@ -321,7 +322,7 @@ class SlideBatch:
         # softmax columns); phase A is the only reader of its own statistics, so the layout is its private choice.
         # for_eval: only meta_forward follows (no train step, no ablation mix): candidates straight from the statistics
         self._layout(COMPACT_STATS and self.Ce > 16, cand_from_stats=bool(for_eval) and CAND_FROM_STATS and self.C > 4)
-        if SCORE_EVENTS is None:
+        if SCORE_EVENTS is None and self.stats_cache is None:
             check(lib().moc_phase_a(C.byref(self.c), ptr(bank.image), _stream()), "moc_phase_a")
             return
         # same four launches, with events around the score pass
@@ -337,7 +338,13 @@ class SlideBatch:
 
     def phase_a_tail(self, bank: Bank):
         """... and the rest: score pass (timed when bench.py collects SCORE_EVENTS), selection, union, candidates."""
-        if SCORE_EVENTS is None:
+        if self.stats_cache is not None:
+            # opt-in (include/moc_hip.h moc_scores_from_cache): the kept rows' statistics from those of an earlier, unmasked
+            # score pass over the same rows and bank -- the same bits, no read of the bags
+            cache, compact = self.stats_cache
+            assert compact == bool(self.c.flags & _lib.MOC_STATS_COMPACT) and cache.size(1) == self.X.size(0)
+            check(lib().moc_scores_from_cache(C.byref(self.c), ptr(cache), cache.size(1), _stream()), "moc_scores_from_cache")
+        elif SCORE_EVENTS is None:
             check(lib().moc_scores(C.byref(self.c), ptr(bank.image), _stream()), "moc_scores")
         else:
             e0, e1 = timed_scores(self, bank)
@@ -377,6 +384,23 @@ class SlideBatch:
             t["tile_ws"] = torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None
             self._ws = (t, MocMetaWs(**{k: ptr(v) for k, v in t.items()}, tile_ws_bytes=nb))
         return self._ws
+
+
+def build_stats_cache(X: torch.Tensor, sizes, starts, bank: "Bank", topj: int, topk: int):
+    """The statistics of EVERY row of X (one unmasked score pass over the slides `sizes` at rows `starts`, which must cover
+    what later passes visit) -> (stats_all [rows of stats, X rows] indexed by the row's position in X, compact flag) -- what
+    SlideBatch.stats_cache takes.  28 bytes per row at two classes."""
+    tmp = SlideBatch(X, sizes, bank.C, bank.Ce, topj, topk, (), x_starts=starts)
+    compact = COMPACT_STATS and bank.Ce > 16
+    tmp._layout(compact)
+    check(lib().moc_mask_compact(C.byref(tmp.c), _stream()), "moc_mask_compact")
+    check(lib().moc_scores(C.byref(tmp.c), ptr(bank.image), _stream()), "moc_scores")
+    ns = (bank.C + 5) if compact else (2 * bank.C + 3)
+    out = torch.zeros((ns, X.size(0)), dtype=torch.float32, device=X.device)
+    off = tmp.row_off_host
+    for b, (st, n) in enumerate(zip(starts, sizes)):      # slot order of an unmasked pass = row order of the slide
+        out[:, st:st + n] = tmp.stats[:ns, off[b]:off[b] + n]
+    return out, compact
 
 
 class CompactBatch(SlideBatch):

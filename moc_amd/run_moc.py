@@ -75,6 +75,9 @@ def get_args(argv=None):
     p.add_argument("--epochs", type=int, default=25, help="main_moc.py:611 hard-codes 25")
     p.add_argument("--synthetic", type=int, default=0, help="run on N generated slides per split instead of files")
     p.add_argument("--seed", type=int, default=None, help="torch.manual_seed before building the meta-learner")
+    p.add_argument("--cache_scores", type=int, default=0,
+                   help="1: keep the per-row statistics of the resident train split from one score pass and re-use them every "
+                        "epoch (the bank is frozen: the same bits as recomputing them, main_moc.py:336-337, without reading the bags)")
     p.add_argument("--folds", type=str, default="",
                    help="comma-separated folds: train them ALL in this process, stepped in lockstep (moc_amd.main_moc.train_runs) -- "
                         "what scripts/moc_train.sh starts as one process per fold.  Every fold's numbers and files are those of "
@@ -174,7 +177,7 @@ def prepare(args, device):
                                mdist.ShardedSplit(bags, blocks[rank], labels, blocks, device, dtype=dt))
                 continue
             bags, labels = synth.make_slide_set(base, sizes, 512, We, C)
-            loaders.append(M.ResidentBags(bags, labels, device, dtype=dt, repeat_num=rep))
+            loaders.append(M.ResidentBags(bags, labels, device, dtype=dt, repeat_num=rep, cache_scores=bool(args.cache_scores) and s == 0))
         return loaders
     task = TASKS[args.dataset]
     labels = task["labels"]
@@ -204,6 +207,7 @@ def prepare(args, device):
         elif args.resident:
             loaders.append(to_resident(sp, device, {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.bag_dtype),
                                        loader_seed_draw=bool(args.loader_seed_draw)))
+            loaders[-1].cache_scores = bool(args.cache_scores) and s_i == 0
         else:
             loaders.append(torch.utils.data.DataLoader(sp, batch_size=1, shuffle=False, num_workers=1))
     return loaders

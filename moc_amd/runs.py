@@ -83,6 +83,16 @@ class TrainRuns:
         if bank.Ce <= 16 and self.reserve > 0:
             for b in self.batches:
                 b.reserve_cus(self.reserve)
+        if os.environ.get("MOC_CACHE_SCORES", "0") == "1" or all(sp.cache_scores for sp in splits):
+            # opt-in (main_moc.ResidentBags cache_scores): the statistics of every row once, then no score pass per epoch
+            all_sizes, all_starts, r0_ = [], [], 0
+            for sp in splits:
+                all_sizes += sp.sizes
+                all_starts += [r0_ + st for st in sp.starts[:-1]]
+                r0_ += sp.X.size(0)
+            cache = engine.build_stats_cache(self.X, all_sizes, all_starts, bank, args.topj, args.topk)
+            for b in self.batches:
+                b.stats_cache = cache
         self.labels = torch.tensor(labels, dtype=torch.int64).to(device)
         self.flags = [torch.empty(T, dtype=torch.uint8).pin_memory() for _ in range(3)]
         self.flag_busy = [None, None, None]

@@ -14,7 +14,7 @@ for R in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,2,4,8").spli
     models, opts, splits = [], [], []
     for r in range(R):
         bags = [synth.make_bag_device(1234 + 1000 * r + i, 15000, D, We, Cc, i % Cc, dev, DT) for i in range(n)]
-        splits.append(M.ResidentBags(bags, [i % Cc for i in range(n)], dev))
+        splits.append(M.ResidentBags(bags, [i % Cc for i in range(n)], dev, cache_scores=(os.environ.get("CACHE") == "1")))
         torch.manual_seed(r)
         m = M.senet(D, 4).to(dev)
         models.append(m); opts.append(torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4))

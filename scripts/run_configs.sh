@@ -4,7 +4,7 @@
 #   bash scripts/run_configs.sh gpurun_out/configs.jsonl
 out=${1:-gpurun_out/configs.jsonl}
 : > "$out"
-run() { timeout -k 10 500 python bench.py --packed-runs 0 --cpu-seconds 8 ${BATCHED:---batched-runs 0} "$@" | tail -1 >> "$out" || exit 1; echo "done: $*" >&2; }
+run() { timeout -k 10 500 python bench.py --packed-runs 0 --cpu-seconds 8 ${BATCHED:---batched-runs 0 --no-cached-extra} "$@" | tail -1 >> "$out" || exit 1; echo "done: $*" >&2; }
 # cfg 1: NSCLC 2-way 1-shot, 256 patches per bag (2 train slides = repeat_num shot x C)
 run --slides 2 --patches 256 --eval-slides 49 --steps 200 --warmup 20 --steady-epochs 200
 # cfg 2: NSCLC 2-way 16-shot, full bags: the headline (fp32 storage), then its 16-bit storage variants

@@ -50,6 +50,8 @@ def test_one_gpu_line(gpu_device):
     assert d["eval_slides_per_sec"] > 10000
     br = d["batched_runs"]["runs_2"]                                  # two runs batched in one process (moc_amd.runs)
     assert br["runs"] == 2 and br["value"] > d["value"] and 0.2 < br["score_pass"]["frac"] < 1.0
+    cs = d["cached_scores"]                                           # opt-in extra: statistics kept from one score pass
+    assert cs["value"] > 5000 and cs["steady_state"] > 0.9 * ss["value"] and "Not `value`" in cs["note"] and cs["batched_runs_8"]["runs"] == 8
     pk = d["packed_runs"]
     assert pk["runs"] == 2 and pk["value"] > 5000 and "vs_one_run" in pk      # two independent runs on the one GPU, timed together
 

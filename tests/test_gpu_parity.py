@@ -1082,7 +1082,7 @@ def test_wave_per_task_topk_gives_the_workgroup_kernels_bits(dev, K, smallest, s
 
 
 # ------------------------------------------------------------------ round 4: the step over the forward's tile records
-def _train_epochs(dev, tile_records, C, D, dtype, sizes, j, K, epochs, seed, discard=(), plant=None):
+def _train_epochs(dev, tile_records, C, D, dtype, sizes, j, K, epochs, seed, discard=(), plant=None, cache_scores=False):
     """`epochs` passes of main_moc.train over a resident split with the tile-record step on or off; -> everything a
     step leaves behind, as host arrays."""
     M, E = _mm(), _engine()
@@ -1097,7 +1097,7 @@ def _train_epochs(dev, tile_records, C, D, dtype, sizes, j, K, epochs, seed, dis
         torch.manual_seed(seed)
         model = M.senet(D, 4).to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
-        res = M.ResidentBags([b_.to(dtype) for b_ in bags], labels, dev)
+        res = M.ResidentBags([b_.to(dtype) for b_ in bags], labels, dev, cache_scores=cache_scores)
         args = H.make_args(C, j, K, discard)
         torch.manual_seed(seed + 7)
         out = {"loss": [], "pooled": [], "topk": [], "path": []}
@@ -1160,3 +1160,23 @@ def test_tile_record_step_falls_back_when_a_tile_holds_the_candidates(dev):
     for k in ("params", "m", "v"):
         np.testing.assert_array_equal(a[k], b[k])
     assert b["path"][-1] == 1000002
+
+
+@pytest.mark.parametrize("C,D,dtype,sizes,j,K", [
+    (2, 512, torch.float32, [3000, 2500, 4100, 2800], 400, 10),
+    (3, 512, torch.bfloat16, [2000, 2600, 1500], 300, 10),
+    (30, 512, torch.bfloat16, [1800, 2200], 100, 10),                 # compact statistics, the wide step
+    (2, 256, torch.float16, [900, 700, 1100], 100, 5),
+])
+def test_cached_statistics_give_the_score_pass_bits(dev, C, D, dtype, sizes, j, K):
+    """Opt-in `cache_scores` (moc_scores_from_cache): the statistics of every row from ONE unmasked score pass, every train
+    pass copying its kept rows' statistics instead of reading the bags (main_moc.py:336-337 recomputes them per visit; the
+    bank is frozen).  A row's statistics do not depend on the mask or on the rows sharing its MFMA tile: three passes end in
+    the same bits -- losses, pooled rows, parameters, moments."""
+    a = _train_epochs(dev, True, C, D, dtype, sizes, j, K, 3, 5151 + C)
+    b = _train_epochs(dev, True, C, D, dtype, sizes, j, K, 3, 5151 + C, cache_scores=True)
+    for e in range(3):
+        np.testing.assert_array_equal(a["loss"][e], b["loss"][e])
+        np.testing.assert_array_equal(a["topk"][e], b["topk"][e])
+    for k in ("params", "m", "v"):
+        np.testing.assert_array_equal(a[k], b[k])
