@@ -571,36 +571,6 @@ def main():
         except Exception as e:  # noqa: BLE001 -- an extra block must not cost the line its `value`
             half_block = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-    # ---- opt-in: the per-row statistics kept from ONE score pass (ResidentBags(cache_scores=True)): no score pass per epoch.
-    # NOT `value` -- its score pass reads the bags every pass, as the reference recomputes them -- an extra block
-    cached_block = None
-    if world == 1 and main_mode == "single" and not a.no_cached_extra and not a.replicas_only:
-        try:
-            ev_keep, engine.SCORE_EVENTS = engine.SCORE_EVENTS, None
-            keep_env = os.environ.get("MOC_CACHE_SCORES")
-            os.environ["MOC_CACHE_SCORES"] = "1"
-            try:
-                rc_ = measure("single", a.steps, a.warmup, 0 if a.no_steady else min(200, a.steady_epochs))
-                cached_runs8 = run_batched(8) if a.batched_runs not in ("", "0") else None
-            finally:
-                if keep_env is None:
-                    os.environ.pop("MOC_CACHE_SCORES", None)
-                else:
-                    os.environ["MOC_CACHE_SCORES"] = keep_env
-            engine.SCORE_EVENTS = ev_keep
-            cached_block = {"value": round(rc_["value"], 1), "unit": "meta-steps/s", "steps": a.steps, "warmup": a.warmup,
-                            "steady_state": rc_["steady"] and rc_["steady"]["value"], "batched_runs_8": cached_runs8,
-                            "note": "opt-in (ResidentBags(cache_scores=True), run_moc --cache_scores 1): the classifier bank is frozen, so a "
-                                    "row's statistics are the same on every visit; they are kept from ONE unmasked score pass (28 B per "
-                                    "2-KiB row) and a train pass copies its kept rows' statistics instead of reading the bags again -- "
-                                    "bit-identical training (tests: test_cached_statistics_give_the_score_pass_bits).  Not `value`: "
-                                    "there the score pass reads the bags every pass, as the reference recomputes feat @ W "
-                                    "(main_moc.py:336-337)"}
-            rc_["loop"] = rc_["res"] = rc_["model"] = None
-            del rc_
-        except Exception as e:  # noqa: BLE001 -- an extra block must not cost the line its `value`
-            cached_block = {"error": f"{type(e).__name__}: {e}"[:300]}
-
     # ---- the modes that are not `value`, from shorter runs of this process, as extra keys (N > 1 only)
     extras = {}
     if world > 1 and (main_mode != "seq" or a.dp_extra):
@@ -741,6 +711,36 @@ def main():
                            "and one step launch per meta-step serve all of them (grid.y / grid.z = run), phase A over all R x n "
                            "slides in one pass.  Per run bit-identical to main_moc.train (tests/test_gpu_runs.py).  The reference's "
                            "scripts/moc_train.sh:11-31 starts these runs as separate processes")
+
+    # ---- opt-in: the per-row statistics kept from ONE score pass (ResidentBags(cache_scores=True)): no score pass per epoch.
+    # NOT `value` -- its score pass reads the bags every pass, as the reference recomputes them -- an extra block
+    cached_block = None
+    if world == 1 and main_mode == "single" and not a.no_cached_extra and not a.replicas_only:
+        try:
+            ev_keep, engine.SCORE_EVENTS = engine.SCORE_EVENTS, None
+            keep_env = os.environ.get("MOC_CACHE_SCORES")
+            os.environ["MOC_CACHE_SCORES"] = "1"
+            try:
+                rc_ = measure("single", a.steps, a.warmup, 0 if a.no_steady else min(200, a.steady_epochs))
+                cached_runs8 = run_batched(8) if a.batched_runs not in ("", "0") else None
+            finally:
+                if keep_env is None:
+                    os.environ.pop("MOC_CACHE_SCORES", None)
+                else:
+                    os.environ["MOC_CACHE_SCORES"] = keep_env
+            engine.SCORE_EVENTS = ev_keep
+            cached_block = {"value": round(rc_["value"], 1), "unit": "meta-steps/s", "steps": a.steps, "warmup": a.warmup,
+                            "steady_state": rc_["steady"] and rc_["steady"]["value"], "batched_runs_8": cached_runs8,
+                            "note": "opt-in (ResidentBags(cache_scores=True), run_moc --cache_scores 1): the classifier bank is frozen, so a "
+                                    "row's statistics are the same on every visit; they are kept from ONE unmasked score pass (28 B per "
+                                    "2-KiB row) and a train pass copies its kept rows' statistics instead of reading the bags again -- "
+                                    "bit-identical training (tests: test_cached_statistics_give_the_score_pass_bits).  Not `value`: "
+                                    "there the score pass reads the bags every pass, as the reference recomputes feat @ W "
+                                    "(main_moc.py:336-337)"}
+            rc_["loop"] = rc_["res"] = rc_["model"] = None
+            del rc_
+        except Exception as e:  # noqa: BLE001 -- an extra block must not cost the line its `value`
+            cached_block = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- CPU baseline: the oracle's train loop AND evaluation loop on the host cores (rank 0, N=1 only), a bounded
     # sample of the same workload (slide-granular: wide configurations do not get through an epoch in the budget)
