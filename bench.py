@@ -12,16 +12,16 @@ One "step" = one meta-step = one slide through mask -> scores -> 4 selectors ->
 union -> meta-learner -> top-K pooling -> CE -> backward -> Adam (main_moc.py:380-410),
 everything the reference's train() does per slide, bags already resident in HBM.
 
-At N > 1 the task stays the SAME 16-shot task and, by default (`--train-mode seq`), the SAME optimisation: the
-exact-sequential mode (moc_amd.dist.train_seq, SURVEY.md section 8e mode 1) shards the bags and phase A over the GPUs,
-all-gathers the compact phase-A results and runs the reference's one-Adam-step-per-slide recurrence on every rank --
-bit-identical to one GPU, hence the reference's AUC; a step is still one slide and `value` counts slides per second.
-Minibatch data parallelism (`--train-mode dp`: one slide per rank per synchronous step, the meta-gradient summed over
-the ranks, one Adam step per N slides) is faster but changes the trajectory -- measured AUC deviations of 0.01-0.2
-from the sequential run at every N and learning-rate rule (profiles/round2_dp_auc_study.jsonl), outside the +-0.002
-bar -- so it is an opt-in extension; `--dp-extra` adds it to an N > 1 run under `minibatch_dp` (strong: the same slides
-sharded, `--scaling`; weak: every rank its own) from shorter runs of the same process; every N > 1 run reports under
-`replicas` what N independent runs (one per GPU, no communication: the reference's scripts/moc_train.sh) deliver together.
+At N > 1 the default (`--train-mode runs`, round 4) is what shards naturally in TRAINING: whole runs.  Every GPU trains
+an independent 16-shot run of its own (the reference's scripts/moc_train.sh starts one process per fold x shot), nothing
+is exchanged, every run is the reference's one-Adam-step-per-slide trajectory bit for bit; a step is one slide, `value`
+counts the slides all ranks consume per second, scaling "weak".  `--train-mode seq` keeps ONE run over the GPUs, exact-
+sequential (moc_amd.dist.train_seq, SURVEY.md section 8e mode 1: bags and phase A sharded, compact results all-gathered,
+the recurrence on every rank -- bit-identical to one GPU, and a latency chain that no second GPU shortens); `--seq-extra`
+adds it to a default run under `exact_sequential`.  Minibatch data parallelism (`--train-mode dp`: one slide per rank per
+synchronous step, the meta-gradient summed over the ranks, one Adam step per N slides) is fast but changes the trajectory
+-- measured AUC deviations of 0.01-0.2 from the sequential run (profiles/round2_dp_auc_study.jsonl), outside the +-0.002
+bar -- so it is an opt-in extension (`--dp-extra`: the `minibatch_dp` block).
 
 Prints ONE JSON line on rank 0.  Extra keys: steady_state (>= 50 whole epochs of the same model in the
 same run: what a training run of many epochs sees, whatever --steps was), roofline (dominant kernel =
@@ -92,9 +92,15 @@ def parse():
                     help="whole epochs of the same model timed right after the --steps region (default: 3,200 epochs = 102,400 "
                          "meta-steps, about 2 s of GPU time: long enough for an outside sampler of GPU activity to see it)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--train-mode", default="seq", choices=["seq", "dp"],
-                    help="N > 1: seq = exact-sequential (one Adam step per slide, bit-identical to one GPU; default); "
-                         "dp = minibatch data parallelism (one step per N slides: changes the trajectory)")
+    ap.add_argument("--train-mode", default="runs", choices=["runs", "seq", "dp"],
+                    help="N > 1: runs = one independent run per GPU, nothing exchanged (default: what shards naturally in "
+                         "training is whole runs -- the reference's scripts/moc_train.sh; every run the reference's trajectory); "
+                         "seq = ONE run over the GPUs, exact-sequential (one Adam step per slide, bit-identical to one GPU: a "
+                         "latency chain that no second GPU shortens); dp = minibatch data parallelism (one step per N slides: "
+                         "changes the trajectory)")
+    ap.add_argument("--seq-extra", action="store_true",
+                    help="N > 1, runs: also measure the exact-sequential mode of ONE run over the GPUs (`exact_sequential` block; "
+                         "its RCCL all-gathers have never run on two distinct devices on this pool, hence opt-in)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="--train-mode dp: strong = the same --slides slides sharded over the ranks (the BASELINE metric); "
                          "weak = every rank its own --slides slides")
@@ -461,7 +467,7 @@ def main():
     if world == 1:
         main_mode = "dp_weak" if a.force_dp else "seq" if a.force_seq else "single"
     else:
-        main_mode = "seq" if a.train_mode == "seq" else "dp_" + a.scaling
+        main_mode = "replicas" if a.train_mode == "runs" else "seq" if a.train_mode == "seq" else "dp_" + a.scaling
     r = measure(main_mode, a.steps, a.warmup, 0 if a.no_steady else a.steady_epochs)
     value, dt, loop, exchange = r["value"], r["dt"], r["loop"], r["exchange"]
     res, model = r["res"], r["model"]
@@ -573,7 +579,19 @@ def main():
 
     # ---- the modes that are not `value`, from shorter runs of this process, as extra keys (N > 1 only)
     extras = {}
-    if world > 1 and (main_mode != "seq" or a.dp_extra):
+    seq_block = None
+    if world > 1 and main_mode == "replicas" and a.seq_extra:
+        try:
+            k2 = max(a.slides, min(a.steps, 10 * a.slides))
+            r2 = measure("seq", k2, min(a.warmup, a.slides), 0)
+            seq_block = {"value": round(r2["value"], 1), "unit": "meta-steps/s (ONE run over all ranks)", "steps": k2, "scaling": "strong",
+                         "note": "exact-sequential: bags and phase A sharded over the GPUs, compact results all-gathered (RCCL), every "
+                                 "rank runs the one-Adam-step-per-slide recurrence -- bit-identical to one GPU; the recurrence is a "
+                                 "latency chain that a second GPU does not shorten"}
+            r2["loop"] = r2["res"] = None
+        except Exception as e:  # noqa: BLE001 -- an extra block must not cost the line its `value`
+            seq_block = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if world > 1 and (main_mode.startswith("dp") or a.dp_extra):
         del res, loop
         r["res"] = r["loop"] = None
         todo = [m for m in ("dp_strong", "dp_weak") if m != main_mode and not (m == "dp_strong" and a.slides % world)]
@@ -595,7 +613,7 @@ def main():
     # ---- N independent runs, one per GPU, no communication at all: how the reference itself uses several GPUs
     # (scripts/moc_train.sh gives every fold x shot its own process and GPU) -- every run the reference's trajectory
     replicas = None
-    if world > 1 and not a.no_replicas:
+    if world > 1 and not a.no_replicas and main_mode != "replicas":
         try:
             k3 = max(a.slides, min(a.steps, 10 * a.slides))
             r3 = measure("replicas", k3, min(a.warmup, a.slides), 0)
@@ -806,6 +824,10 @@ def main():
     if rank == 0:
         if world == 1 and main_mode != "seq":
             par = "single GPU, one Adam step per slide"
+        elif main_mode == "replicas":
+            par = (f"runs x GPUs: {world} independent training runs ({a.slides} slides of its own each), one per GPU, NOTHING exchanged "
+                   "-- what shards naturally in training is whole runs (the reference's scripts/moc_train.sh: one process per fold x "
+                   "shot); every run is the reference's one-Adam-step-per-slide trajectory, bit for bit")
         elif main_mode == "seq":
             par = (f"seq{world}: exact-sequential -- bags and phase A (mask, scores, selectors, union) sharded over the {world} GPUs "
                    f"in contiguous balanced blocks of {a.slides // world}-{(a.slides + world - 1) // world} slides, unpadded compact results "
@@ -820,7 +842,7 @@ def main():
             "metric": "meta-steps/sec (train), slides/sec (eval) on 16-shot NSCLC synthetic bags",
             "value": round(value, 1), "unit": "meta-steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 5), "higher_is_better": True,
-            "scaling": "weak" if main_mode in ("single", "dp_weak") else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if main_mode in ("single", "dp_weak", "replicas") else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name(a), "bag_storage": a.dtype, "arithmetic": "fp32 accumulate (MFMA)",
                        "parallelism": par},
             "steady_state": r["steady"],
@@ -837,6 +859,8 @@ def main():
                 out["rccl_version"] = f"unavailable ({type(e).__name__})"
         if replicas:
             out["replicas"] = replicas
+        if seq_block:
+            out["exact_sequential"] = seq_block
         if packed:
             out["packed_runs"] = packed
         if batched:
@@ -844,7 +868,7 @@ def main():
         if cached_block:
             out["cached_scores"] = cached_block
         if extras:
-            out["minibatch_dp" if main_mode == "seq" else "other_modes"] = dict(
+            out["minibatch_dp" if main_mode in ("seq", "replicas") else "other_modes"] = dict(
                 extras, note="synchronous minibatch data parallelism: one Adam step per N slides -- an opt-in extension "
                              "(--train-mode dp), its AUC is NOT within +-0.002 of the sequential reference "
                              "(profiles/round2_dp_auc_study.jsonl)")

@@ -1,8 +1,8 @@
 """bench.py as the driver runs it, on the GPU box: the one-GPU line carries what the contract asks for (value over
 exactly --steps steps, a steady_state block, roofline measured live, traffic null or matched), and `--gpus 2` starts
-its own ranks -- rehearsed with both ranks on the one card (MOC_BENCH_ONE_DEVICE=1, gloo): the exact-sequential mode
-is `value`, minibatch data parallelism an extra block, and the ranks end with bit-identical parameters (bench.py
-asserts that itself)."""
+its own ranks -- rehearsed with both ranks on the one card (MOC_BENCH_ONE_DEVICE=1, gloo): runs x GPUs is `value`, the
+exact-sequential mode and minibatch data parallelism extra blocks (their ranks end with bit-identical parameters:
+bench.py asserts that itself)."""
 import json
 import os
 import subprocess
@@ -56,15 +56,26 @@ def test_one_gpu_line(gpu_device):
     assert pk["runs"] == 2 and pk["value"] > 5000 and "vs_one_run" in pk      # two independent runs on the one GPU, timed together
 
 
-def test_gpus_2_starts_its_own_ranks_and_reports_the_exact_sequential_mode(gpu_device):
+def test_gpus_2_starts_its_own_ranks_and_reports_runs_x_gpus(gpu_device):
+    """N > 1: `value` is runs x GPUs (one independent run per rank, nothing exchanged, scaling weak); the exact-sequential
+    mode of ONE run over the ranks and minibatch data parallelism are opt-in extra blocks."""
     d = _bench("--gpus", "2", "--steps", "32", "--warmup", "32", "--no-eval", "--steady-epochs", "2", "--dp-exchange", "auto", "--dp-extra",
-               "--batched-runs", "0",
+               "--seq-extra", "--batched-runs", "0",
                env={"MOC_BENCH_ONE_DEVICE": "1"})
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 100
-    assert d["config"]["parallelism"].startswith("seq2: exact-sequential")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 100
+    assert d["config"]["parallelism"].startswith("runs x GPUs: 2 independent training runs")
     assert "rehearsal" in d and d["ranks_seen"] == 2 and "rccl_version" in d
+    sq = d["exact_sequential"]
+    assert sq["value"] > 100 and sq["scaling"] == "strong" and "bit-identical" in sq["note"]
     mb = d["minibatch_dp"]
     assert mb["dp_strong"]["value"] > 100 and mb["dp_weak"]["value"] > 100 and mb["dp_strong"]["exchange"] == "p2p"
     assert "NOT within" in mb["note"]
+    assert "replicas" not in d                                        # (it IS `value` now)
+
+
+def test_gpus_2_train_mode_seq_is_still_there(gpu_device):
+    d = _bench("--gpus", "2", "--steps", "32", "--warmup", "32", "--no-eval", "--steady-epochs", "2", "--train-mode", "seq", "--batched-runs", "0",
+               env={"MOC_BENCH_ONE_DEVICE": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"].startswith("seq2: exact-sequential")
     rep = d["replicas"]
     assert rep["value"] > 100 and rep["scaling"] == "weak" and "no collective" in rep["note"]
