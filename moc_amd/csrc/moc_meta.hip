@@ -1789,9 +1789,9 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
 // repeating the pooling for itself -- restructured around what the phase stamps of round 4 showed (profiles/NOTES.md):
 // the step is a chain of dependent memory round trips and of dependent instructions; neither gets shorter by adding
 // threads, only by taking round trips and instructions out of the chain.
-//  * A workgroup is FOUR waves and owns 256 columns of ONE hidden unit of W1 (grid D / 256 x H: 128 workgroups at
-//    D = 512); the workgroups of column block 0 also own b1[h] and W2[:, h], workgroup (0, 0) b2.  Every sum over the
-//    pairs runs in the same order as in pool_w1_step_kernel: the same bits.
+//  * A workgroup is FOUR waves and owns 256 columns of ONE hidden unit of W1, or -- the last column block, the "tail"
+//    workgroup of the hidden unit -- b1[h] and W2[:, h] (h = 0: b2 too) and no column (grid (D / 256 + 1) x H: 192
+//    workgroups at D = 512).  Every sum over the pairs runs in the same order as in pool_w1_step_kernel: the same bits.
 //  * The kernel's arguments are its own compact struct, ordered by first use, and every cache line of them is touched
 //    at the top in ONE wait: the general step's 700 bytes of arguments were five scalar-cache misses one after the other
 //    in front of the first load.
@@ -1804,14 +1804,16 @@ __global__ __launch_bounds__(1024) void pool_w1_step_kernel(FusedArgs g, float* 
 //    while the fourth wave does the cross entropy; the parameters this workgroup steps were requested at the top.
 // Falls back to the full scores inside the kernel when the records cannot prove exactness.
 struct TileStepArgs {
-    // ---- first cache line: what the first loads need
+    // ---- first cache line (64 bytes): what the first loads need -- they are issued before the other lines are touched
     const unsigned long long* tkey;
     const uint32_t* trho;
     int64_t slot0;
-    int cap, ntile_bound, C, K, D, slide0, PS_CAP, xdt;
+    int cap, ntile_bound, C, K, D, slide0;
+    int n_runs, slide_stride;       // batched runs (n_runs > 0): see the end of the struct
     const int32_t* n_sel;
-    const int64_t* labels;
     // ---- what this thread steps
+    const int64_t* labels;
+    int PS_CAP, xdt;
     float *W1, *m_W1, *v_W1;
     const float* W2;
     float *b1, *m_b1, *v_b1, *b2, *m_b2, *v_b2, *m_W2, *v_W2;
@@ -1846,7 +1848,6 @@ struct TileStepArgs {
     int64_t stride;
     // ---- batched runs (n_runs > 0): grid.z = run; run r steps the meta-learner whose tensors lie par_stride floats (W2 in:
     // w2_stride, W2 out: w2out_stride, operand image: img_stride bytes) behind run 0's, on slide slide0 + r * slide_stride
-    int n_runs, slide_stride;
     int64_t par_stride, w2_stride, w2out_stride, img_stride;
     int64_t base_r[MOC_MAX_RUNS], slot0_r[MOC_MAX_RUNS];
     int32_t cap_r[MOC_MAX_RUNS], ntb_r[MOC_MAX_RUNS];
@@ -1855,31 +1856,33 @@ struct TileStepArgs {
 template <int VQ>
 __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    moc_kernarg_touch<sizeof(TileStepArgs)>();           // every cache line of the arguments, requested side by side, one wait
+    static_assert(offsetof(TileStepArgs, n_sel) + 8 <= 64, "the first loads' arguments must share the first cache line");
     // batched runs: this workgroup's run -- its slide, its region of the records, the offsets of its tensors (the argument
     // block itself is not modified and its arrays are read through kernarg_at: either would send all of it to scratch)
     int b = a.slide0;
-    int64_t base = a.base, slot0 = a.slot0, po = 0, w2o = 0, w2outo = 0, imgo = 0;
+    int64_t base = 0, slot0 = a.slot0, po = 0, w2o = 0, w2outo = 0, imgo = 0;
     int cap = a.cap, ntile_bound = a.ntile_bound;
-    if (a.n_runs > 0) {
+    const bool runs = a.n_runs > 0;
+    if (runs) {
         const int run = blockIdx.z;
         b += run * a.slide_stride;
-        base = kernarg_at<int64_t>(offsetof(TileStepArgs, base_r) + 8 * (size_t)run);
         slot0 = kernarg_at<int64_t>(offsetof(TileStepArgs, slot0_r) + 8 * (size_t)run);
         cap = kernarg_at<int32_t>(offsetof(TileStepArgs, cap_r) + 4 * (size_t)run);
         ntile_bound = kernarg_at<int32_t>(offsetof(TileStepArgs, ntb_r) + 4 * (size_t)run);
-        po = (int64_t)run * a.par_stride; w2o = (int64_t)run * a.w2_stride; w2outo = (int64_t)run * a.w2out_stride;
-        imgo = (int64_t)run * a.img_stride;
     }
-    const int C = a.C, K = a.K, D = a.D, PS_CAP = a.PS_CAP;
+    const int C = a.C, K = a.K, D = a.D;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int cb = blockIdx.x, h = blockIdx.y;
-    const bool wg0 = cb == 0 && h == 0;                                              // (of its run)
+    // The last column block is the TAIL workgroup of its hidden unit: it owns b1[h] and W2[:, h] (h = 0: b2 too) and no
+    // column of W1 -- on a W1 workgroup those few elements' sums and second Adam update ran after the wave's own W1 work
+    const bool tail_wg = cb == (D >> 8);                  // (grid.x = D / 256 + 1; not gridDim: that pulls 256 bytes of hidden arguments into the segment)
+    const bool wg0 = cb == 0 && h == 0;                                              // (of its run: publishes the slide's outputs)
     constexpr int CL = 64;                                                            // candidates per class
     MOC_STAMP(10);
     MOC_STAMP_MIN(33);
     MOC_STAMP_MAX(34);
-    // ---- round trip 1, requested before anything else: the keys of this wave's first class (wave w: classes w, w + 4, ...)
+    // ---- round trip 1, requested before anything else -- before the other argument lines are even touched: the keys of
+    // this wave's first class (wave w: classes w, w + 4, ...)
     unsigned long long key[VQ];
     uint32_t rho[VQ / 4];
 #define MOC_TILE_KEYS(c)                                                                                              \
@@ -1896,22 +1899,34 @@ __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs
         }                                                                                                             \
     }
     if (wave < C) MOC_TILE_KEYS(wave)
+    __builtin_amdgcn_sched_barrier(0);
+    moc_kernarg_touch<sizeof(TileStepArgs)>();           // every other line of the arguments, side by side, one wait
+    const int PS_CAP = a.PS_CAP;
+    base = a.base;
+    if (runs) {
+        const int run = blockIdx.z;
+        base = kernarg_at<int64_t>(offsetof(TileStepArgs, base_r) + 8 * (size_t)run);
+        po = (int64_t)run * a.par_stride; w2o = (int64_t)run * a.w2_stride; w2outo = (int64_t)run * a.w2out_stride;
+        imgo = (int64_t)run * a.img_stride;
+    }
     // ... then what this thread steps (independent of the pooling; it queues behind the keys).  The small tensors' owners
     // sit in different waves: their sums over the pairs run side by side, not one after the other in one wave
     const int d = cb * 256 + t;                                                      // this thread's column of W1[h]
     float pw = 0.f, pm = 0.f, pv = 0.f;
     float pT = 0.f, pTm = 0.f, pTv = 0.f;                                            // this thread's element of W2 / b1 / b2
     int tail = -1;                                                                   // flat index past W1: b1 | W2 | b2
-    if (cb == 0) {
+    if (tail_wg) {
         if (t < 4) tail = H + t * H + h;                                             // W2[i = t][h]: wave 0
         else if (t == 64) tail = h;                                                  // b1[h]: wave 1
-        else if (wg0 && t >= 128 && t < 132) tail = H + 4 * H + (t - 128);           // b2[i]: wave 2
+        else if (h == 0 && t >= 128 && t < 132) tail = H + 4 * H + (t - 128);        // b2[i]: wave 2
     }
     float w2v = 0.f;
     if (t < 4) w2v = a.W2[w2o + t * H + h];
     if (a.apply_adam) {
-        const int64_t e = po + h * D + d;
-        pw = a.W1[e]; pm = a.m_W1[e]; pv = a.v_W1[e];
+        if (!tail_wg) {
+            const int64_t e = po + h * D + d;
+            pw = a.W1[e]; pm = a.m_W1[e]; pv = a.v_W1[e];
+        }
         if (tail >= H + 4 * H) { const int64_t i = po + tail - 5 * H; pT = a.b2[i]; pTm = a.m_b2[i]; pTv = a.v_b2[i]; }
         else if (tail >= H) { const int64_t i = po + tail - H; pTm = a.m_W2[i]; pTv = a.v_W2[i]; }
         else if (tail >= 0) { pT = a.b1[po + tail]; pTm = a.m_b1[po + tail]; pTv = a.v_b1[po + tail]; }
@@ -2126,7 +2141,7 @@ __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs
                 const int c = (int)(((unsigned)p * kinv) >> 16);
                 h1s[p] = a.H1[(base + topk_s[c * K + (p - c * k)]) * H + h];
             }
-        } else {                                                                     // row pieces -> fp32 in LDS: four in flight per wave
+        } else if (!tail_wg) {                                                       // row pieces -> fp32 in LDS: four in flight per wave
             const int esz = a.xdt == MOC_F32 ? 4 : 2;
             const int64_t col0 = (int64_t)cb * 256 * esz;
             for (int p0 = wave; p0 < P; p0 += 12) {
@@ -2206,7 +2221,7 @@ __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs
     // ---- gradients of the owned elements, every sum over the pairs in ascending order (operands four pairs at a time:
     // the additions stay in order, the LDS reads do not wait for each other)
     float gr = 0.f;
-    {
+    if (!tail_wg) {
         int p = 0;
         for (; p + 4 <= P; p += 4) {
             const float4 d4 = *reinterpret_cast<const float4*>(dhs + p);
@@ -2242,14 +2257,14 @@ __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs
         for (; p < P; ++p) gt += dhs[p];
     }
     if (!a.apply_adam) {                                  // gradient out (data-parallel step with a collective)
-        a.g_W1[h * D + d] = gr;
+        if (!tail_wg) a.g_W1[h * D + d] = gr;
         if (tail >= H + 4 * H) a.g_b2[tail - 5 * H] = gt;
         else if (tail >= H) a.g_W2[tail - H] = gt;
         else if (tail >= 0) a.g_b1[tail] = gt;
         return;
     }
     const float gs = ak.grad_scale;
-    {
+    if (!tail_wg) {
         const int64_t e = po + h * D + d;
         adam_update(pw, pm, pv, gr * gs, ak);
         a.W1[e] = pw; a.m_W1[e] = pm; a.v_W1[e] = pv;
@@ -3149,7 +3164,7 @@ TileStepArgs tile_step_args(const moc_batch_t* B, const moc_meta_t* M, const moc
 // launches it for `runs` meta-learners (grid.z); the largest tile bound of any run picks the keys per lane
 int launch_tile_step(const moc_batch_t* B, const TileStepArgs& ta, int runs, hipStream_t s) {
     const size_t sm = tiles_step_smem(B, ta.PS_CAP);
-    const dim3 grid(B->D / 256, H, runs);
+    const dim3 grid(B->D / 256 + 1, H, runs);             // D / 256 column blocks of W1 + the tail workgroup, per hidden unit
     int tb = ta.ntile_bound;
     for (int r = 0; r < ta.n_runs; ++r) tb = ta.ntb_r[r] > tb ? ta.ntb_r[r] : tb;
 #define MOC_TILES_LAUNCH(VQ) pool_w1_step_tiles_kernel<VQ><<<grid, 256, sm, s>>>(ta)
