@@ -380,7 +380,10 @@ class SlideBatch:
                 W2_alt=torch.empty((4, HIDDEN), **f32),
                 pair_row=torch.empty(Cc * K, dtype=torch.int64, device=dev), n_pair=torch.zeros(1, **i32))
             # tile records (include/moc_hip.h moc_meta_ws_t.tile_ws): what the training forward leaves for the step kernel
-            nb = lib().moc_tile_ws_bytes(T, n, Cc) if TILE_RECORDS else 0
+            # (only where the tile-record step can run -- narrow banks -- and only for batches that train: masked ones and
+            # the gathered batches of the exact-sequential mode; an evaluation batch of 3 M rows x 30 classes would carry 1 GB)
+            trains = self.mask is not None or isinstance(self, CompactBatch)
+            nb = lib().moc_tile_ws_bytes(T, n, Cc) if (TILE_RECORDS and trains and Cc <= 16 and K <= 16 and Cc * K <= 64) else 0
             t["tile_ws"] = torch.empty(nb, dtype=torch.uint8, device=dev) if nb else None
             self._ws = (t, MocMetaWs(**{k: ptr(v) for k, v in t.items()}, tile_ws_bytes=nb))
         return self._ws
