@@ -2314,13 +2314,16 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     float* dpool = pooled_s + C;
     int* ncand = reinterpret_cast<int*>(dpool + C);
     int* topk_s = ncand + C;                                                         // [C][K]
-    float* dz = reinterpret_cast<float*>(topk_s + PMAX);                             // [P][4]
-    float* h1o = dz + (size_t)PMAX * 4;                                              // [P][4]
-    unsigned* mask = reinterpret_cast<unsigned*>(h1o + (size_t)PMAX * 4);            // [P][2]
-    int* sidx_s = reinterpret_cast<int*>(mask + (size_t)PMAX * 2);                   // [P]
+    // (16-byte aligned; sixteen rows of slack behind the pairs: the product below walks them in groups of sixteen)
+    // (the offset is rounded, not the address: a pointer rebuilt from an integer is a FLAT pointer to the compiler)
+    float* dz = reinterpret_cast<float*>(smem + (((reinterpret_cast<unsigned char*>(topk_s + PMAX) - smem) + 15) & ~(ptrdiff_t)15));   // [P + 16][4]
+    float* h1o = dz + (size_t)(PMAX + 16) * 4;                                       // [P][4]
+    const int PM = (PMAX + 16 + 3) & ~3;                                             // pairs per plane of the ReLU masks
+    unsigned* mask = reinterpret_cast<unsigned*>(h1o + (size_t)PMAX * 4);            // [2][PM]: bits of hidden units 0..31 | 32..63
+    int* sidx_s = reinterpret_cast<int*>(mask + (size_t)PM * 2);                     // [P]
     float* W2s = reinterpret_cast<float*>(sidx_s + PMAX);                            // [4][H]
     float* red = W2s + 4 * H;                                                        // [32]
-    int64_t* prow_s = reinterpret_cast<int64_t*>((reinterpret_cast<uintptr_t>(red + 32) + 7) & ~(uintptr_t)7);   // [P]
+    int64_t* prow_s = reinterpret_cast<int64_t*>(smem + (((reinterpret_cast<unsigned char*>(red + 32) - smem) + 7) & ~(ptrdiff_t)7));   // [P]
 
     // ---- operands that do not depend on this slide: requested first, consumed last.
     // The W1 gradient of this workgroup is a [64 x DS] tile product on the fp32 matrix cores: wave w < 4*DS/16
@@ -2383,7 +2386,8 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     // pairs per class k <= 16, pair numbers < 1024: p / k = (p * ceil(2^16 / k)) >> 16 exactly (no integer division: with
     // sixteen waves on the CU the five of them per thread below were half of this phase)
     const unsigned kinv = k > 0 ? (65536u + (unsigned)k - 1u) / (unsigned)k : 0u;
-    for (int p = t; p < 2 * P; p += 1024) mask[p] = 0u;
+    for (int p = t; p < 2 * P; p += 1024) mask[(p >= P ? PM - P : 0) + p] = 0u;
+    if (t < 64) dz[P * 4 + t] = 0.f;                       // the slack rows: pairs P .. P + 15 contribute nothing
     // the pairs' hidden rows are requested here, with the pair operands (both hang on topk_s only): their ReLU bits
     // are ORed into the masks after the barrier below
     float4 hv_pre[5];
@@ -2416,7 +2420,7 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     auto take_hidden = [&](int e, const float4& hv) {
         const int p = e >> 4, v = e & 15;
         const unsigned bits = (hv.x > 0.f ? 1u : 0u) | (hv.y > 0.f ? 2u : 0u) | (hv.z > 0.f ? 4u : 0u) | (hv.w > 0.f ? 8u : 0u);
-        if (bits) atomicOr(&mask[2 * p + (v >> 3)], bits << ((v & 7) * 4));
+        if (bits) atomicOr(&mask[(v >> 3) * PM + p], bits << ((v & 7) * 4));
         if (v == wg) *reinterpret_cast<float4*>(h1o + p * 4) = hv;
     };
 #pragma unroll
@@ -2427,15 +2431,22 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     __syncthreads();                                       // masks complete
     MOC_STAMP(43);
     // ---- W1 gradient: dW1[h][d] = sum_p dh[p][h] x[p][d], pairs in chunks of WD_PCH through `region`:
-    // [PCH][DS] pieces of the pairs' rows as stored + [PCH][64] fp32 dh, then v_mfma_f32_16x16x4_f32 over p
+    // [PCH][DS] pieces of the pairs' rows as stored, then v_mfma_f32_16x16x4_f32 over p.  dh is never staged: per group of
+    // sixteen pairs a tile wave forms dh[16 pairs][its 16 hidden units] = dz[16][4] W2[4][16] with ONE matrix instruction
+    // (k = the four gates), whose result registers are, lane for lane, the A operands of the group's four gradient
+    // instructions -- lane (li, kq) ends with dh[pair 4 kq + i][h0 + li] in register i, which is A[m = li][k = kq] of the
+    // instruction that takes the pairs {i, 4 + i, 8 + i, 12 + i} of the group as its k.  The ReLU mask is one AND per
+    // element (a sign-extended bit of the pair's mask word).  What this replaced: every workgroup writing all P x 64
+    // values of dh to LDS first (19 rounds x ~25 instructions x 16 waves on one CU: 7.0 of the step's 25 us by the stamps,
+    // instruction issue, not latency) and reading them back as A fragments.  (Forming dh in the loop with the VALU -- the
+    // old fmaf chain per element -- was measured first: 18 us, sixteen waves x 18 vector instructions per MFMA.)
     f32x4_t gacc = {0.f, 0.f, 0.f, 0.f};
     {
         const int ppr = DS * esz / 16;                     // 16-B pieces per pair
         unsigned char* xraw = region;                                              // [PCH][DS * esz]
-        float* dh_s = reinterpret_cast<float*>(region + (size_t)WD_PCH * DS * esz); // [PCH][64]
         for (int c0 = 0; c0 < P; c0 += WD_PCH) {
             const int n = P - c0 < WD_PCH ? P - c0 : WD_PCH;
-            const int n4 = (n + 3) & ~3;
+            const int n16 = (n + 15) & ~15;                // (<= WD_PCH: a multiple of 32)
             if (c0 > 0) __syncthreads();                   // previous chunk consumed
             // (requesting the next chunk's pieces a chunk ahead needs registers this 1024-thread kernel does not
             // have: at its 128-register cap hipcc waits for them at once and parks them in scratch -- measured
@@ -2458,55 +2469,45 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
                     if (e < n * ppr) *reinterpret_cast<uint4*>(xraw + (size_t)e * 16) = piece[u];
                 }
             }
+            // the rows behind the last pair of a group of sixteen: zero (their dh is zero, but 0 x whatever bytes lie here is not)
+            for (int e = n * ppr + t; e < n16 * ppr; e += 1024) *reinterpret_cast<uint4*>(xraw + (size_t)e * 16) = uint4{0u, 0u, 0u, 0u};
             if (c0 == 0) MOC_STAMP(50);
-            {   // dh of the chunk: thread = (hidden unit t & 63, pair t >> 6 + 16 m); its four W2 entries stay in registers
-                const int h = t & 63;
-                const float w0 = W2s[h], w1 = W2s[H + h], w2 = W2s[2 * H + h], w3 = W2s[3 * H + h];
-#pragma unroll 8
-                for (int m = 0; m < WD_PCH / 16; ++m) {                // (unrolled by eight: the rounds' LDS reads overlap)
-                    const int pp = (t >> 6) + 16 * m;
-                    if (pp < n4) {
-                        float v = 0.f;
-                        if (pp < n && (mask[2 * (c0 + pp) + (h >> 5)] >> (h & 31) & 1u)) {
-                            const float4 z = *reinterpret_cast<const float4*>(dz + (c0 + pp) * 4);
-                            v = fmaf(z.w, w3, fmaf(z.z, w2, fmaf(z.y, w1, z.x * w0)));
-                        }
-                        dh_s[pp * 64 + (h ^ ((pp & 3) << 4))] = v;      // (columns swizzled by the pair: the A-fragment reads below hit 64 banks)
-                    }
-                }
-            }
-            if (c0 == 0) MOC_STAMP(51);
             __syncthreads();
             if (c0 == 0) MOC_STAMP(52);
             if (in_product) {
                 const int kq = lane >> 4, li = lane & 15, cc = (d0 - d_lo) + li;
-                // this wave's share of the chunk's k-steps: all of them, or (ksplit) the first / second half, cut at a multiple of 4
-                const int half = ((n4 >> 1) + 3) & ~3;
-                const int kb = (ksplit && wave >= 8) ? half : 0, ke = (ksplit && wave < 8) ? half : n4;
-                // eight k = 4 steps at a time: their sixteen LDS reads in flight together (one step at a time the read
-                // latency was exposed 32 times per chunk); storage type decided once, outside
+                const int hh = h0 + li;                                 // this lane's hidden unit
+                const float w2b = W2s[kq * H + hh];                     // B of the dh product: [gate kq][hidden unit]
+                const unsigned msh = (unsigned)(hh & 31);
+                // this wave's share of the chunk's groups: all of them, or (ksplit) the first / second half
+                const int half = (((n16 >> 4) + 1) >> 1) << 4;
+                const int kb = (ksplit && wave >= 8) ? half : 0, ke = (ksplit && wave < 8) ? half : n16;
+                const float* dzp = dz + (size_t)(c0 + li) * 4 + kq;                           // A of the dh product: [pair li][gate kq]
+                const uint4* mkp = reinterpret_cast<const uint4*>(mask + (size_t)(hh >> 5) * PM + c0 + 4 * kq);   // words of the lane's four pairs
                 auto product = [&](auto kind) {
                     constexpr int XK = decltype(kind)::value;           // 0 fp32, 1 bf16, 2 fp16
-                    auto xval = [&](int pp) -> float {
-                        if constexpr (XK == 0) return reinterpret_cast<const float*>(xraw)[(size_t)pp * DS + cc];
-                        else if constexpr (XK == 2) return moc_f16_to_f32(reinterpret_cast<const uint16_t*>(xraw)[(size_t)pp * DS + cc]);
-                        else return moc_bf16_to_f32(reinterpret_cast<const uint16_t*>(xraw)[(size_t)pp * DS + cc]);
+                    typedef typename std::conditional<XK == 0, float, uint16_t>::type xs_t;
+                    const xs_t* xp = reinterpret_cast<const xs_t*>(xraw) + (size_t)(4 * kq) * DS + cc;   // row ks + 4 kq + i: + (ks + i) * DS
+                    auto xcv = [&](xs_t v) -> float {
+                        if constexpr (XK == 0) return v;
+                        else if constexpr (XK == 2) return moc_f16_to_f32(v);
+                        else return moc_bf16_to_f32(v);
                     };
-                    int ks = kb;
-                    for (; ks + 32 <= ke; ks += 32) {
-                        float av[8], bv[8];
+                    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+                    for (int ks = kb; ks < ke; ks += 16) {
+                        const float za = dzp[ks * 4];
+                        const uint4 m = mkp[ks >> 2];
+                        const xs_t x0 = xp[(size_t)(ks + 0) * DS], x1 = xp[(size_t)(ks + 1) * DS], x2 = xp[(size_t)(ks + 2) * DS],
+                                   x3 = xp[(size_t)(ks + 3) * DS];
+                        const f32x4_t dh = __builtin_amdgcn_mfma_f32_16x16x4f32(za, w2b, zero4, 0, 0, 0);
+                        const unsigned mk[4] = {m.x, m.y, m.z, m.w};
+                        const float xv[4] = {xcv(x0), xcv(x1), xcv(x2), xcv(x3)};
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int pp = ks + 4 * u + kq;
-                            av[u] = dh_s[pp * 64 + ((h0 + li) ^ (kq << 4))];       // pp & 3 == kq (ks is a multiple of 4)
-                            bv[u] = pp < n ? xval(pp) : 0.f;
+                        for (int i = 0; i < 4; ++i) {
+                            const unsigned on = (unsigned)__builtin_amdgcn_sbfe((int)mk[i], msh, 1u);      // 0 or all ones
+                            gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(__float_as_uint(dh[i]) & on), xv[i], gacc, 0, 0, 0);
                         }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], gacc, 0, 0, 0);
-                    }
-                    for (; ks < ke; ks += 4) {
-                        const int pp = ks + kq;
-                        gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(dh_s[pp * 64 + ((h0 + li) ^ (kq << 4))], pp < n ? xval(pp) : 0.f, gacc, 0, 0, 0);
                     }
                 };
                 if (a.xdt == MOC_F32) product(std::integral_constant<int, 0>{});
@@ -3086,16 +3087,17 @@ int wide_cap(const moc_batch_t* B) {
 }
 size_t wide_region(const moc_batch_t* B, int pch) {
     const size_t lists = (size_t)B->C * wide_cap(B) * 8;
-    const size_t rows = (size_t)pch * ((B->D / 16) * moc_elem_size(B->dtype) + 64 * sizeof(float));   // row pieces + dh of one chunk
+    const size_t rows = (size_t)pch * ((B->D / 16) * moc_elem_size(B->dtype));   // row pieces of one chunk (dh is formed in the product loop)
     return ((lists > rows ? lists : rows) + 15) & ~(size_t)15;
 }
 size_t wide_smem(const moc_batch_t* B, int pch) {
     const size_t C = B->C, PK = C * B->topk;
-    return wide_region(B, pch) + C * 16 * 8 + C * 4 * 3 + PK * 4 + PK * 16 * 2 + PK * 8 + PK * 4 + (4 * H + 32) * 4 + 8 + PK * 8;
+    return wide_region(B, pch) + C * 16 * 8 + C * 4 * 3 + PK * 4 + PK * 16 * 2 + PK * 8 + PK * 4 + (4 * H + 32) * 4 + 8 + PK * 8
+           + 16 + 16 * 16 + 2 * 20 * 4;      // dz aligned to 16 bytes, its sixteen slack rows, the mask planes' padding
 }
-// pairs per chunk of the W1 gradient: all C * K of them in ONE chunk when its row pieces + dh fit beside the rest
-// (EBRAINS-30: 300 pairs, 97 KiB at bf16) -- one gather round trip and one barrier pair instead of three; else the
-// largest multiple of 32 that fits, at least WD_PCH_MIN
+// pairs per chunk of the W1 gradient: all C * K of them in ONE chunk when its row pieces fit beside the rest
+// (EBRAINS-30: 300 pairs, 38 KiB at fp32; the 64-way shape: 640 pairs, 80 KiB at fp16) -- one gather round trip and one
+// barrier instead of one per chunk; else the largest multiple of 32 that fits, at least WD_PCH_MIN
 int wide_pch(const moc_batch_t* B) {
     int pch = (B->C * B->topk + 31) & ~31;
     while (pch > WD_PCH_MIN && wide_smem(B, pch) > (size_t)FS_MAX_DYN_LDS) pch -= 32;

@@ -26,7 +26,7 @@ m, kept = engine.draw_row_masks(batch.total); batch.set_mask(m, kept); batch.pha
 meta = engine.MetaState(model, opt)
 h = lib(); h.moc_debug_stamps.restype = C.c_int; h.moc_debug_stamps.argtypes = [C.c_void_p, C.c_int]
 names = {0: "fwd begin", 1: "fwd mfma done", 2: "fwd end", 40: "step begin", 41: "top-K picked up, CE done", 42: "pair operands requested",
-         43: "hidden rows / masks done", 50: "chunk 0: rows in LDS, next requested", 51: "chunk 0: dh written", 52: "chunk 0: barrier",
+         43: "hidden rows / masks done", 50: "chunk 0: rows in LDS, next requested", 52: "chunk 0: barrier",
          53: "chunk 0: MFMAs done", 44: "W1 gradient chunks done", 45: "small gradients done", 46: "step end"}
 acc = {}
 for rep in range(20):
