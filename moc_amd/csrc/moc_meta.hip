@@ -2141,19 +2141,22 @@ __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs
                 const int c = (int)(((unsigned)p * kinv) >> 16);
                 h1s[p] = a.H1[(base + topk_s[c * K + (p - c * k)]) * H + h];
             }
-        } else if (!tail_wg) {                                                       // row pieces -> fp32 in LDS: four in flight per wave
+        } else if (!tail_wg) {                                                       // row pieces -> fp32 in LDS: eight in flight per wave
+            // (twenty-four rows per round over the three waves: K = 10, C = 2 is ONE round trip; with four per wave it was two)
             const int esz = a.xdt == MOC_F32 ? 4 : 2;
             const int64_t col0 = (int64_t)cb * 256 * esz;
-            for (int p0 = wave; p0 < P; p0 += 12) {
-                const int p1 = p0 + 3, p2 = p0 + 6, p3 = p0 + 9;
-                const unsigned char* r0 = a.X + prid[p0] * (int64_t)D * esz + col0;
-                const unsigned char* r1 = a.X + prid[p1 < P ? p1 : p0] * (int64_t)D * esz + col0;
-                const unsigned char* r2 = a.X + prid[p2 < P ? p2 : p0] * (int64_t)D * esz + col0;
-                const unsigned char* r3 = a.X + prid[p3 < P ? p3 : p0] * (int64_t)D * esz + col0;
-                float4 v0, v1, v2, v3;
+            constexpr int RF = 8;
+            for (int p0 = wave; p0 < P; p0 += 3 * RF) {
+                const unsigned char* rp[RF];
+#pragma unroll
+                for (int u = 0; u < RF; ++u) {
+                    const int pu = p0 + 3 * u;
+                    rp[u] = a.X + prid[pu < P ? pu : p0] * (int64_t)D * esz + col0;
+                }
+                float4 v[RF];
                 if (a.xdt == MOC_F32) {
-                    v0 = reinterpret_cast<const float4*>(r0)[lane]; v1 = reinterpret_cast<const float4*>(r1)[lane];
-                    v2 = reinterpret_cast<const float4*>(r2)[lane]; v3 = reinterpret_cast<const float4*>(r3)[lane];
+#pragma unroll
+                    for (int u = 0; u < RF; ++u) v[u] = reinterpret_cast<const float4*>(rp[u])[lane];
                 } else {
                     const bool f16 = a.xdt == MOC_F16;
                     auto widen = [&](uint2 raw) {
@@ -2167,14 +2170,17 @@ __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs
                         }
                         return o;
                     };
-                    const uint2 u0 = reinterpret_cast<const uint2*>(r0)[lane], u1 = reinterpret_cast<const uint2*>(r1)[lane];
-                    const uint2 u2 = reinterpret_cast<const uint2*>(r2)[lane], u3 = reinterpret_cast<const uint2*>(r3)[lane];
-                    v0 = widen(u0); v1 = widen(u1); v2 = widen(u2); v3 = widen(u3);
+                    uint2 raw[RF];
+#pragma unroll
+                    for (int u = 0; u < RF; ++u) raw[u] = reinterpret_cast<const uint2*>(rp[u])[lane];
+#pragma unroll
+                    for (int u = 0; u < RF; ++u) v[u] = widen(raw[u]);
                 }
-                reinterpret_cast<float4*>(xs + (size_t)p0 * 256)[lane] = v0;
-                if (p1 < P) reinterpret_cast<float4*>(xs + (size_t)p1 * 256)[lane] = v1;
-                if (p2 < P) reinterpret_cast<float4*>(xs + (size_t)p2 * 256)[lane] = v2;
-                if (p3 < P) reinterpret_cast<float4*>(xs + (size_t)p3 * 256)[lane] = v3;
+#pragma unroll
+                for (int u = 0; u < RF; ++u) {
+                    const int pu = p0 + 3 * u;
+                    if (pu < P) reinterpret_cast<float4*>(xs + (size_t)pu * 256)[lane] = v[u];
+                }
             }
         }
     }

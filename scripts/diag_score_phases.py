@@ -2,7 +2,7 @@
 (make -C moc_amd/csrc stamps; built into build/ by scripts/_stamps.py): locate + issue / wait for loads / LDS reads +
 MFMAs / row epilogue, summed over the units of wave 0 of workgroup 0.
 
-    python scripts/diag_score_phases.py [classes 30] [dim 512] [slides 120] [rows 15000] [masked 1] [compact statistics 1]
+    python scripts/diag_score_phases.py [classes 30] [dim 512] [slides 120] [rows 15000] [masked 1] [compact statistics 1] [bf16|fp16|fp32]
 """
 import ctypes as C
 import os
@@ -19,12 +19,13 @@ from moc_amd import engine, synth  # noqa: E402
 from moc_amd._lib import check, lib, ptr  # noqa: E402
 
 Cc, D, n_slides, N, masked, compact = [int(v) for v in (sys.argv[1:7] + ["30", "512", "120", "15000", "1", "1"][len(sys.argv) - 1:])]
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[sys.argv[7] if len(sys.argv) > 7 else "bf16"]
 dev = torch.device("cuda:0")
 W, We = synth.make_bank(1, D, Cc)
-X = torch.randn(n_slides * N, D, device=dev).to(torch.bfloat16)
+X = torch.randn(n_slides * N, D, device=dev).to(DT)
 mask = (torch.rand(n_slides * N) > 0.5) if masked else None
 b = engine.SlideBatch(X, [N] * n_slides, Cc, Cc + 4, 400, 10, mask=mask)
-bank = engine.Bank.get(W, We, torch.bfloat16, dev)
+bank = engine.Bank.get(W, We, DT, dev)
 b.c.flags = 1 if compact else 0                      # MOC_STATS_COMPACT
 check(lib().moc_mask_compact(C.byref(b.c), engine._stream()), "mc")
 hh = lib()
