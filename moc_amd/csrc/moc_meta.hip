@@ -1814,6 +1814,7 @@ struct TileStepArgs {
     // ---- what this thread steps
     const int64_t* labels;
     int PS_CAP, xdt;
+    int tail_inside, pad0_;         // != 0: no tail workgroups (grid.x = D / 256), column block 0 owns the hidden unit's small elements too
     float *W1, *m_W1, *v_W1;
     const float* W2;
     float *b1, *m_b1, *v_b1, *b2, *m_b2, *v_b2, *m_W2, *v_W2;
@@ -1875,7 +1876,11 @@ __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs
     const int cb = blockIdx.x, h = blockIdx.y;
     // The last column block is the TAIL workgroup of its hidden unit: it owns b1[h] and W2[:, h] (h = 0: b2 too) and no
     // column of W1 -- on a W1 workgroup those few elements' sums and second Adam update ran after the wave's own W1 work
-    const bool tail_wg = cb == (D >> 8);                  // (grid.x = D / 256 + 1; not gridDim: that pulls 256 bytes of hidden arguments into the segment)
+    // (Batched runs of four or more keep the small elements on column block 0 instead -- tail_inside: R x 128 workgroups of
+    // which a CU holds four, so that eight runs are ONE round of workgroups and not two; a few threads' second sum and
+    // second Adam update behind their W1 work cost a single run 0.6 us, a launch of eight runs wins 8 us.)
+    const bool tail_wg = !a.tail_inside && cb == (D >> 8); // (grid.x = D / 256 + 1; not gridDim: that pulls 256 bytes of hidden arguments into the segment)
+    const bool tail_role = a.tail_inside ? cb == 0 : tail_wg;
     const bool wg0 = cb == 0 && h == 0;                                              // (of its run: publishes the slide's outputs)
     constexpr int CL = 64;                                                            // candidates per class
     MOC_STAMP(10);
@@ -1915,7 +1920,7 @@ __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs
     float pw = 0.f, pm = 0.f, pv = 0.f;
     float pT = 0.f, pTm = 0.f, pTv = 0.f;                                            // this thread's element of W2 / b1 / b2
     int tail = -1;                                                                   // flat index past W1: b1 | W2 | b2
-    if (tail_wg) {
+    if (tail_role) {
         if (t < 4) tail = H + t * H + h;                                             // W2[i = t][h]: wave 0
         else if (t == 64) tail = h;                                                  // b1[h]: wave 1
         else if (h == 0 && t >= 128 && t < 132) tail = H + 4 * H + (t - 128);        // b2[i]: wave 2
@@ -3174,7 +3179,7 @@ TileStepArgs tile_step_args(const moc_batch_t* B, const moc_meta_t* M, const moc
 // launches it for `runs` meta-learners (grid.z); the largest tile bound of any run picks the keys per lane
 int launch_tile_step(const moc_batch_t* B, const TileStepArgs& ta, int runs, hipStream_t s) {
     const size_t sm = tiles_step_smem(B, ta.PS_CAP);
-    const dim3 grid(B->D / 256 + 1, H, runs);             // D / 256 column blocks of W1 + the tail workgroup, per hidden unit
+    const dim3 grid(B->D / 256 + (ta.tail_inside ? 0 : 1), H, runs);   // D / 256 column blocks of W1 (+ the tail workgroup), per hidden unit
     int tb = ta.ntile_bound;
     for (int r = 0; r < ta.n_runs; ++r) tb = ta.ntb_r[r] > tb ? ta.ntb_r[r] : tb;
 #define MOC_TILES_LAUNCH(VQ) pool_w1_step_tiles_kernel<VQ><<<grid, 256, sm, s>>>(ta)
@@ -3513,6 +3518,9 @@ extern "C" int moc_train_steps_runs(const moc_batch_t* B, const moc_meta_t* M, c
         if (int rc = launch_forward(B, &Mt, ws, b, 1, use_bits, s, true, R, cur_stride)) return rc;
         TileStepArgs ta = tile_step_args(B, &Mt, ws, labels, b, use_bits, k, nxt, 1, nullptr);
         ta.n_runs = R->n_runs; ta.slide_stride = R->slide_stride;
+        // four runs or more: throughput, not one run's latency, is what a launch is about -- no tail workgroups
+        static const int tail_env = getenv("MOC_RUNS_TAIL_INSIDE") ? atoi(getenv("MOC_RUNS_TAIL_INSIDE")) : -1;   // diagnostic override
+        ta.tail_inside = tail_env >= 0 ? tail_env : (R->n_runs >= 4 ? 1 : 0);
         ta.par_stride = R->par_stride; ta.img_stride = R->image_stride; ta.w2_stride = cur_stride; ta.w2out_stride = nxt_stride;
         for (int r = 0; r < R->n_runs; ++r) {
             const int sl = b + r * R->slide_stride;
