@@ -2374,59 +2374,114 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
         else { pS = a.b1[small]; pSm = a.m_b1[small]; pSv = a.v_b1[small]; }
     }
     int64_t base;
-    int k;
+    int k, P;
+    unsigned kinv;
+    float4 hv_pre[5];
+    // the pairs' hidden rows: requested as soon as the pooled rows' indices are in LDS, their ReLU bits ORed into the masks
+    // further down
+    auto request_hidden = [&]() {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int e = t + q * 1024;
+            hv_pre[q] = float4{0.f, 0.f, 0.f, 0.f};
+            if (e < P * 16) {
+                const int p = e >> 4, c = (int)(((unsigned)p * kinv) >> 16);
+                hv_pre[q] = *reinterpret_cast<const float4*>(a.H1 + (base + topk_s[c * K + (p - c * k)]) * H + (e & 15) * 4);
+            }
+        }
+    };
+    auto zero_masks = [&]() {
+        for (int p = t; p < 2 * P; p += 1024) mask[(p >= P ? PM - P : 0) + p] = 0u;
+        if (t < 64) dz[P * 4 + t] = 0.f;                   // the slack rows: pairs P .. P + 15 contribute nothing
+    };
     if (external_pool) {
-        // more than 8192 selected rows possible: the top-K came from topk_mean_kernel (one workgroup per class,
-        // radix select); pick it up, add loss / argmax / d loss
+        // more than 8192 selected rows possible: the top-K came from topk_mean_kernel (one workgroup per class); pick it up,
+        // add loss / argmax / d loss.  Thread e < C K owns the pooled row (class e / K, place e % K): its operands -- row id,
+        // four candidate scores, gates -- are requested from the REGISTER that holds its index, before the index has even
+        // been to LDS, and are under way while wave 0 does the cross entropy; the hidden rows (which need other threads'
+        // indices) follow behind the first barrier.  (Before: indices -> LDS -> barrier -> cross entropy -> barrier -> the
+        // operands' round trip -> barrier: 5.4 of the step's 15.7 us by the stamps.)
         base = a.base_host >= 0 ? a.base_host : a.row_off[b];
         const int y = (int)a.labels[b];
-        for (int e = t; e < C * K; e += 1024) topk_s[e] = a.topk_idx[(int64_t)b * C * K + e];
-        if (t < C) pooled_s[t] = a.pooled[(int64_t)b * C + t];
+        const int PK = C * K;
+        const int own_idx = a.topk_idx[(int64_t)b * PK + (t < PK ? t : PK - 1)];
         k = a.topk_cnt[(int64_t)b * C];
+        const float pooled_v = a.pooled[(int64_t)b * C + (t < C ? t : 0)];
+        P = C * k;
+        // pairs per class k <= 16, pair numbers < 1024: p / k = (p * ceil(2^16 / k)) >> 16 exactly (no integer division)
+        kinv = k > 0 ? (65536u + (unsigned)k - 1u) / (unsigned)k : 0u;
+        const unsigned kinvK = (65536u + (unsigned)K - 1u) / (unsigned)K;
+        const int own_c = (int)(((unsigned)t * kinvK) >> 16), own_pos = t - own_c * K;
+        const bool own = t < PK && own_pos < k;
+        int64_t own_row = 0;
+        float sc[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 lam = {0.f, 0.f, 0.f, 0.f};
+        if (own) {
+            own_row = a.sel_row[base + own_idx];
+            const float* cd = a.cand + base + own_idx;
+            sc[0] = cd[(int64_t)own_c * a.stride]; sc[1] = cd[(int64_t)(C + own_c) * a.stride];
+            sc[2] = cd[(int64_t)(2 * C) * a.stride]; sc[3] = cd[(int64_t)(2 * C + 1) * a.stride];
+            lam = *reinterpret_cast<const float4*>(a.gates + (base + own_idx) * 4);
+        }
+        if (t < PK) topk_s[t] = own_idx;
+        if (t < C) pooled_s[t] = pooled_v;
+        if (t < 4 * H) W2s[t] = w2r;
+        zero_masks();
         __syncthreads();
+        request_hidden();
         ce_wave0<32>(a, b, C, y, pooled_s, dpool, wg == 0);
+        __syncthreads();
+        MOC_STAMP(41);
+        if (own) {
+            const int pr = own_c * k + own_pos;
+            sidx_s[pr] = own_idx;
+            prow_s[pr] = own_row;
+            const float lv[4] = {lam.x, lam.y, lam.z, lam.w};
+            const float gk = dpool[own_c] / (float)k;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                dz[pr * 4 + i] = (a.use_bits >> i & 1u) ? gk * sc[i] * lv[i] * (1.f - lv[i]) : 0.f;
+        }
     } else {
         const PoolLds L = {list, wmax, pooled_s, dpool, ncand, topk_s};
         k = pool_phase<8, 32, 2>(a, b, L, PS_CAP, wg == 0, pooled_out, topk_idx_out, topk_cnt_out, &base);
-    }
-    if (t < 4 * H) W2s[t] = w2r;
-    __syncthreads();
-    MOC_STAMP(41);
-    // ---- pairs
-    const int P = C * k;
-    // pairs per class k <= 16, pair numbers < 1024: p / k = (p * ceil(2^16 / k)) >> 16 exactly (no integer division: with
-    // sixteen waves on the CU the five of them per thread below were half of this phase)
-    const unsigned kinv = k > 0 ? (65536u + (unsigned)k - 1u) / (unsigned)k : 0u;
-    for (int p = t; p < 2 * P; p += 1024) mask[(p >= P ? PM - P : 0) + p] = 0u;
-    if (t < 64) dz[P * 4 + t] = 0.f;                       // the slack rows: pairs P .. P + 15 contribute nothing
-    // the pairs' hidden rows are requested here, with the pair operands (both hang on topk_s only): their ReLU bits
-    // are ORed into the masks after the barrier below
-    float4 hv_pre[5];
+        if (t < 4 * H) W2s[t] = w2r;
+        __syncthreads();
+        MOC_STAMP(41);
+        // ---- pairs
+        P = C * k;
+        kinv = k > 0 ? (65536u + (unsigned)k - 1u) / (unsigned)k : 0u;
+        zero_masks();
+        request_hidden();
+        for (int p = t; p < P; p += 1024) {
+            const int c = (int)(((unsigned)p * kinv) >> 16), sidx = topk_s[c * K + (p - c * k)];
+            sidx_s[p] = sidx;
+            prow_s[p] = a.sel_row[base + sidx];
+            const float* cd = a.cand + base + sidx;
+            const float sc[4] = {cd[(int64_t)c * a.stride], cd[(int64_t)(C + c) * a.stride],
+                                 cd[(int64_t)(2 * C) * a.stride], cd[(int64_t)(2 * C + 1) * a.stride]};
+            const float4 lam = *reinterpret_cast<const float4*>(a.gates + (base + sidx) * 4);
+            const float lv[4] = {lam.x, lam.y, lam.z, lam.w};
+            const float gk = dpool[c] / (float)k;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        const int e = t + q * 1024;
-        hv_pre[q] = float4{0.f, 0.f, 0.f, 0.f};
-        if (e < P * 16) {
-            const int p = e >> 4, c = (int)(((unsigned)p * kinv) >> 16);
-            hv_pre[q] = *reinterpret_cast<const float4*>(a.H1 + (base + topk_s[c * K + (p - c * k)]) * H + (e & 15) * 4);
+            for (int i = 0; i < 4; ++i)
+                dz[p * 4 + i] = (a.use_bits >> i & 1u) ? gk * sc[i] * lv[i] * (1.f - lv[i]) : 0.f;
         }
-    }
-    for (int p = t; p < P; p += 1024) {
-        const int c = (int)(((unsigned)p * kinv) >> 16), sidx = topk_s[c * K + (p - c * k)];
-        sidx_s[p] = sidx;
-        prow_s[p] = a.sel_row[base + sidx];
-        const float* cd = a.cand + base + sidx;
-        const float sc[4] = {cd[(int64_t)c * a.stride], cd[(int64_t)(C + c) * a.stride],
-                             cd[(int64_t)(2 * C) * a.stride], cd[(int64_t)(2 * C + 1) * a.stride]};
-        const float4 lam = *reinterpret_cast<const float4*>(a.gates + (base + sidx) * 4);
-        const float lv[4] = {lam.x, lam.y, lam.z, lam.w};
-        const float gk = dpool[c] / (float)k;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            dz[p * 4 + i] = (a.use_bits >> i & 1u) ? gk * sc[i] * lv[i] * (1.f - lv[i]) : 0.f;
     }
     __syncthreads();
     MOC_STAMP(42);
+    // the first row pieces of the W1 gradient are requested below, right behind the hidden rows' ReLU bits (whose registers
+    // they take over: both at once spill) and in front of the barrier and the small gradients: they land in LDS in the chunk loop
+    const int DSb = DS * esz;                              // bytes of a pair's piece
+    const int ppr = DSb / 16;                              // 16-B pieces per pair: 4, 8 or 16 -- shifts, no division
+    const int ppr_sh = ppr == 4 ? 2 : ppr == 8 ? 3 : ppr == 16 ? 4 : ppr == 2 ? 1 : 0;
+    // (one piece per call, returned by value, the four of a batch in named variables: an array filled under a branch, or
+    // handed to a lambda by reference, goes to scratch memory)
+    auto request_piece = [&](int c0, int n, int e) -> uint4 {
+        const int ec = e < n * ppr ? e : n * ppr - 1;
+        const int pp = ec >> ppr_sh, v = ec - (pp << ppr_sh);
+        return *reinterpret_cast<const uint4*>(a.X + (prow_s[c0 + pp] * D + d_lo) * esz + v * 16);
+    };
     // hidden rows of the pairs: ReLU mask (64 bits) and the four values this workgroup owns
     auto take_hidden = [&](int e, const float4& hv) {
         const int p = e >> 4, v = e & 15;
@@ -2439,6 +2494,12 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
         if (t + q * 1024 < P * 16) take_hidden(t + q * 1024, hv_pre[q]);
     for (int e = t + 5 * 1024; e < P * 16; e += 1024)           // more than 320 pairs
         take_hidden(e, *reinterpret_cast<const float4*>(a.H1 + (base + sidx_s[e >> 4]) * H + (e & 15) * 4));
+    const int n_first = P < WD_PCH ? P : WD_PCH;
+    uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {};
+    if (P > 0) {
+        pre0 = request_piece(0, n_first, t); pre1 = request_piece(0, n_first, t + 1024);
+        pre2 = request_piece(0, n_first, t + 2048); pre3 = request_piece(0, n_first, t + 3072);
+    }
     __syncthreads();                                       // masks complete
     MOC_STAMP(43);
     // ---- small gradients: 16 + 4 (+ 4) sums over the pairs, one or two per wave, pairs strided over the lanes.  They run
@@ -2483,33 +2544,33 @@ __global__ __launch_bounds__(1024) void pool_w1_step_wide_kernel(FusedArgs g, fl
     f32x4_t gacc = {0.f, 0.f, 0.f, 0.f};
     if (P == 0) small_gradients();                         // (no pair at all: the sums are zeros, but they are written)
     {
-        const int ppr = DS * esz / 16;                     // 16-B pieces per pair
         unsigned char* xraw = region;                                              // [PCH][DS * esz]
         for (int c0 = 0; c0 < P; c0 += WD_PCH) {
             const int n = P - c0 < WD_PCH ? P - c0 : WD_PCH;
             const int n16 = (n + 15) & ~15;                // (<= WD_PCH: a multiple of 32)
             if (c0 > 0) __syncthreads();                   // previous chunk consumed
-            // (requesting the next chunk's pieces a chunk ahead needs registers this 1024-thread kernel does not
-            // have: at its 128-register cap hipcc waits for them at once and parks them in scratch -- measured
-            // 3 % slower than loading each chunk where it is used)
             // (up to four pieces per thread requested before the first is stored: one round trip for a whole chunk of
-            // up to 4096 pieces -- ppr is 4, 8 or 16: shifts, no division)
-            const int ppr_sh = ppr == 4 ? 2 : ppr == 8 ? 3 : ppr == 16 ? 4 : ppr == 2 ? 1 : 0;
-            for (int e0 = 0; e0 < n * ppr; e0 += 4096) {
-                uint4 piece[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int e = e0 + t + u * 1024;
-                    const int ec = e < n * ppr ? e : n * ppr - 1;
-                    const int pp = ec >> ppr_sh, v = ec - (pp << ppr_sh);
-                    piece[u] = *reinterpret_cast<const uint4*>(a.X + (prow_s[c0 + pp] * D + d_lo) * esz + v * 16);
-                }
-                if (c0 == 0 && e0 == 0) small_gradients();
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int e = e0 + t + u * 1024;
-                    if (e < n * ppr) *reinterpret_cast<uint4*>(xraw + (size_t)e * 16) = piece[u];
-                }
+            // up to 4096 pieces; the first batch of the first chunk was requested above and the small gradients run in front
+            // of its stores.  Requesting EVERY chunk's pieces a chunk ahead needs registers this 1024-thread kernel does not
+            // have: at its 128-register cap hipcc waits for them at once and parks them in scratch -- measured 3 % slower)
+            unsigned char* xr = region;
+            auto store_batch = [&](int e0, uint4 q0, uint4 q1, uint4 q2, uint4 q3) {
+                const int e = e0 + t;
+                if (e < n * ppr) *reinterpret_cast<uint4*>(xr + (size_t)e * 16) = q0;
+                if (e + 1024 < n * ppr) *reinterpret_cast<uint4*>(xr + (size_t)(e + 1024) * 16) = q1;
+                if (e + 2048 < n * ppr) *reinterpret_cast<uint4*>(xr + (size_t)(e + 2048) * 16) = q2;
+                if (e + 3072 < n * ppr) *reinterpret_cast<uint4*>(xr + (size_t)(e + 3072) * 16) = q3;
+            };
+            int e0 = 0;
+            if (c0 == 0) {                                 // the batch requested above
+                small_gradients();
+                store_batch(0, pre0, pre1, pre2, pre3);
+                e0 = 4096;
+            }
+            for (; e0 < n * ppr; e0 += 4096) {
+                const uint4 q0 = request_piece(c0, n, e0 + t), q1 = request_piece(c0, n, e0 + t + 1024);
+                const uint4 q2 = request_piece(c0, n, e0 + t + 2048), q3 = request_piece(c0, n, e0 + t + 3072);
+                store_batch(e0, q0, q1, q2, q3);
             }
             // the rows behind the last pair of a group of sixteen: zero (their dh is zero, but 0 x whatever bytes lie here is not)
             for (int e = n * ppr + t; e < n16 * ppr; e += 1024) *reinterpret_cast<uint4*>(xraw + (size_t)e * 16) = uint4{0u, 0u, 0u, 0u};
