@@ -263,17 +263,28 @@ def main():
 
     def fence():
         # (the host spins on an event of the main stream first: hipDeviceSynchronize's blocking wait wakes up 20-30 us
-        # after the GPU is done, 5 % of a 20-step region; the synchronize that follows then returns at once)
+        # after the GPU is done, 5 % of a 20-step region; the synchronize that follows still takes 21-25 us with every
+        # stream idle -- MOC_BENCH_TRACE=1 prints the four host times -- and stays inside the region, as the contract asks)
         e = fence.event                  # (one event object, re-recorded: creating one costs 3 us of a 0.5-ms region)
+        st = fence.stamps
+        if st is not None:
+            st.append(time.perf_counter())
         e.record()
+        if st is not None:
+            st.append(time.perf_counter())
         while not e.query():
             pass
+        if st is not None:
+            st.append(time.perf_counter())
         torch.cuda.synchronize()
+        if st is not None:
+            st.append(time.perf_counter())
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
     fence.event = torch.cuda.Event()
+    fence.stamps = None                  # MOC_BENCH_TRACE=1: host times inside the fence that ends the timed region
 
     def max_over_ranks(dt):
         if world > 1:
@@ -289,6 +300,8 @@ def main():
         possibly partial.  Every pass is told the length of the pass that follows it, so that its phase A -- issued a
         pass ahead on the side stream, as in a run of many epochs -- is for the right visits even when --warmup or
         --steps is not a whole number of epochs."""
+
+        trace = []                       # MOC_BENCH_TRACE=1: host time per pass, printed after the regions
 
         def __init__(self, res, model, opt, mode):
             self.res, self.model, self.opt, self.mode = res, model, opt, mode
@@ -319,7 +332,7 @@ def main():
                 else:
                     M.train(self.model, res, self.opt, dev, args)
                 if TRACE:
-                    print(f"trace: pass of {m} (next {nxt}, then {nxt2}) issued in {(time.perf_counter() - t_in) * 1e6:.0f} us", file=sys.stderr)
+                    Loop.trace.append(f"pass of {m} (next {nxt}, then {nxt2}) issued in {(time.perf_counter() - t_in) * 1e6:.0f} us")
             res.repeat_num = None
             res.next_pass_len = None
             res.pass_after_next_len = None
@@ -422,10 +435,20 @@ def main():
             assert ranks_agree(model), "ranks disagree on the collective path"
         if engine.SCORE_EVENTS is not None:
             engine.SCORE_EVENTS.clear()
+        if TRACE:
+            Loop.trace.clear()
+            fence.stamps = []
         t0 = time.perf_counter()
         loop.run(timed, then=after_timed[0], then2=after_timed[1])
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
+        if TRACE:
+            st = fence.stamps
+            fence.stamps = None
+            print(f"trace: timed region {dt * 1e6:.0f} us: run() returned at {(st[0] - t0) * 1e6:.0f}, event recorded {(st[1] - t0) * 1e6:.0f}, "
+                  f"event done {(st[2] - t0) * 1e6:.0f}, synchronize returned {(st[3] - t0) * 1e6:.0f}", file=sys.stderr)
+            for ln in Loop.trace + getattr(M.train, "trace_host", [])[-len(timed):]:
+                print("trace:   " + ln, file=sys.stderr)
         if TRACE and getattr(M.train, "trace_events", None):
             for n_, e0_, e1_ in M.train.trace_events[-len(timed):]:
                 print(f"trace: timed pass of {n_}: GPU time between the pass's first launch and its last kernel {e0_.elapsed_time(e1_) * 1e3:.0f} us; "
