@@ -1852,7 +1852,13 @@ struct TileStepArgs {
     int64_t par_stride, w2_stride, w2out_stride, img_stride;
     int64_t base_r[MOC_MAX_RUNS], slot0_r[MOC_MAX_RUNS];
     int32_t cap_r[MOC_MAX_RUNS], ntb_r[MOC_MAX_RUNS];
+    // ---- the slide the NEXT step works on (same work arrays; -1: none): its selected rows are pulled toward the Infinity
+    // Cache by the waves that have no class to pool (runs: the slide after each run's own, when next_base >= 0)
+    int64_t next_base;
+    int sink_off, pad1_;            // byte offset of 1 KiB of LDS nobody reads (the prefetch's LDS-DMA destination)
+    int64_t next_base_r[MOC_MAX_RUNS];
 };
+static_assert(sizeof(TileStepArgs) <= 1024, "a kernel-argument segment over 1 KiB takes a slow launch path (profiles/NOTES.md)");
 
 template <int VQ>
 __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs a) {
@@ -1937,6 +1943,38 @@ __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs
         else if (tail >= 0) { pT = a.b1[po + tail]; pTm = a.m_b1[po + tail]; pTv = a.v_b1[po + tail]; }
     }
     MOC_STAMP(19);
+    // ---- the next slide's selected rows, its row ids and its candidate columns: one dword of every 128-byte line, by the
+    // waves with no class to pool (C < 4), results never used.  The forward of the next step then finds them in the
+    // Infinity Cache: with 492 MB of score pass streaming through that cache every pass, nothing of a slide is left in it
+    // from the pass before (a 1-GB copy between two passes of steps with nothing else on the GPU: 16.8 -> 18.5 us per
+    // step, scripts/diag_mall.py).  Inline asm: the compiler's wait insertion does not see these loads, nobody waits for
+    // them (s_endpgm does).
+    if (wave >= C && a.next_base >= 0) {
+        int64_t nb = a.next_base;
+        if (runs) nb = kernarg_at<int64_t>(offsetof(TileStepArgs, next_base_r) + 8 * (size_t)blockIdx.z);
+        const int S2 = a.n_sel[b + 1];
+        const int esz_p = a.xdt == MOC_F32 ? 4 : 2;
+        const int lpr = D * esz_p / 128;                                            // lines per row
+        const int iw = 4 - C;                                                       // waves of a workgroup that come here
+        const int gx = (D >> 8) + (a.tail_inside ? 0 : 1);
+        const int g0 = ((h * gx + cb) * iw + (wave - C)) * 64 + lane, G = gx * H * iw * 64;
+        // (LDS-DMA into 256 sacrificial bytes per wave: a load into a register that nobody reads leaves the compiler free to
+        // re-use that register while the load is still in flight -- the first form of this did, and faulted)
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        float* sinkw = reinterpret_cast<float*>(smem + a.sink_off) + (wave - C) * 64;
+        for (int L = g0; L < S2 * lpr; L += G) {
+            const int r = L / lpr;
+            const unsigned char* pl = a.X + a.sel_row[nb + r] * (int64_t)D * esz_p + (int64_t)(L - r * lpr) * 128;
+            __builtin_amdgcn_global_load_lds((gptr_t)pl, (lptr_t)sinkw, 4, 0, 0);
+        }
+        const int ncol = 2 * C + 2, lpc = (S2 + 31) >> 5;                           // candidate columns, lines per column
+        for (int L = g0; L < ncol * lpc; L += G) {
+            const int c = L / lpc;
+            const float* pl = a.cand + (int64_t)c * a.stride + nb + (int64_t)(L - c * lpc) * 32;
+            __builtin_amdgcn_global_load_lds((gptr_t)pl, (lptr_t)sinkw, 4, 0, 0);
+        }
+    }
     AdamCoef ak = a.adam;
     if (a.adam_tab) ak = a.adam_tab[a.adam_ctr[0] + a.adam_pos];
     const int S = a.n_sel[b];
@@ -3139,9 +3177,11 @@ bool fused_step_ok(const moc_batch_t* B, const moc_meta_ws_t* ws) {
 
 // the one-launch step over the forward's tile records (pool_w1_step_tiles_kernel): the shapes of pool_w1_step_kernel, when
 // the caller has given the record arrays
+// (+ 1 KiB at the very end: the prefetch's sink)
+constexpr size_t TILES_SINK = 1024;
 size_t tiles_step_smem(const moc_batch_t* B, int cap) {
     const size_t C = B->C, K = B->topk, P = C * K, CL = 64;
-    return P * 32 + P * 256 * 4 + (P + 4) * 4 + P * 16 + C * cap * 8 + C * 8 + P * 8 + C * CL * 4 + C * 16 * 4 + C * 4 * 4 + P * 4 + P * 4 + 16 + 64;
+    return TILES_SINK + P * 32 + P * 256 * 4 + (P + 4) * 4 + P * 16 + C * cap * 8 + C * 8 + P * 8 + C * CL * 4 + C * 16 * 4 + C * 4 * 4 + P * 4 + P * 4 + 16 + 64;
 }
 bool tiles_ok(const moc_batch_t* B, const moc_meta_ws_t* ws) {
     static const bool off = getenv("MOC_TILE_RECORDS") && atoi(getenv("MOC_TILE_RECORDS")) == 0;   // diagnostic: the round-3 step
@@ -3226,6 +3266,8 @@ TileStepArgs tile_step_args(const moc_batch_t* B, const moc_meta_t* M, const moc
     ta.b1 = M->b1; ta.m_b1 = M->m_b1; ta.v_b1 = M->v_b1; ta.b2 = M->b2; ta.m_b2 = M->m_b2; ta.v_b2 = M->v_b2;
     ta.m_W2 = M->m_W2; ta.v_W2 = M->v_W2;
     ta.base = B->row_off_host[slide]; ta.adam = k;
+    ta.next_base = -1;
+    ta.sink_off = (int)(tiles_step_smem(B, ta.PS_CAP) - TILES_SINK);
     if (tab) { ta.adam_tab = tab->tab; ta.adam_ctr = tab->ctr; ta.adam_pos = tab->pos; }
     ta.apply_adam = apply_adam; ta.use_bits = use_bits; ta.img_dt = B->dtype;
     ta.H1 = ws->H1; ta.X = (const unsigned char*)B->X;
@@ -3254,9 +3296,11 @@ int launch_tile_step(const moc_batch_t* B, const TileStepArgs& ta, int runs, hip
     return MOC_OK;
 }
 
+// next_slide: the slide the step after this one works on, in the same work arrays (-1: none / unknown) -- the tile-record
+// step pulls its selected rows toward the Infinity Cache
 int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_t* ws, const int64_t* labels,
                       int slide, uint32_t use_bits, const AdamCoef& k, float* W2out, hipStream_t s,
-                      int apply_adam = 1, const P2pArgs* x = nullptr, const StepTab* tab = nullptr) {
+                      int apply_adam = 1, const P2pArgs* x = nullptr, const StepTab* tab = nullptr, int next_slide = -1) {
     FusedArgs g = {};
     if (x) g.x = *x;
     FinishArgs& a = g.f;
@@ -3302,6 +3346,8 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
     if (g.x.world <= 1 && tiles_ok(B, ws)) {               // over the forward's tile records (the forward was told to leave them)
         fused_step_attrs();
         TileStepArgs ta = tile_step_args(B, M, ws, labels, slide, use_bits, k, W2out, apply_adam, tab);
+        static const bool prefetch = !(getenv("MOC_STEP_PREFETCH") && atoi(getenv("MOC_STEP_PREFETCH")) == 0);   // diagnostic: off
+        if (prefetch && next_slide >= 0 && next_slide < B->n_slides && B->C < 4) ta.next_base = B->row_off_host[next_slide];
         return launch_tile_step(B, ta, 1, s);
     }
     const size_t smem = fused_step_smem(B, cap);
@@ -3583,9 +3629,14 @@ extern "C" int moc_train_steps_runs(const moc_batch_t* B, const moc_meta_t* M, c
         static const int tail_env = getenv("MOC_RUNS_TAIL_INSIDE") ? atoi(getenv("MOC_RUNS_TAIL_INSIDE")) : -1;   // diagnostic override
         ta.tail_inside = tail_env >= 0 ? tail_env : (R->n_runs >= 4 ? 1 : 0);
         ta.par_stride = R->par_stride; ta.img_stride = R->image_stride; ta.w2_stride = cur_stride; ta.w2out_stride = nxt_stride;
+        static const bool prefetch = !(getenv("MOC_STEP_PREFETCH") && atoi(getenv("MOC_STEP_PREFETCH")) == 0);   // diagnostic: off
+        // (launches of four runs or more are bound by workgroup slots, not by one run's latency: the prefetch cost eight
+        // batched runs 3.6 %)
+        if (prefetch && t + 1 < n && B->C < 4 && R->n_runs < 4) ta.next_base = 0;     // (any value >= 0: the runs' own are in next_base_r)
         for (int r = 0; r < R->n_runs; ++r) {
             const int sl = b + r * R->slide_stride;
             ta.base_r[r] = B->row_off_host[sl];
+            ta.next_base_r[r] = t + 1 < n ? B->row_off_host[sl + 1] : -1;
             int cap_, tb_;
             tile_region(B, sl, &ta.slot0_r[r], &cap_, &tb_);
             ta.cap_r[r] = cap_; ta.ntb_r[r] = tb_;
@@ -3695,7 +3746,7 @@ int issue_fused_pass(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_w
         else k = adam_coef(M, M->step + 1 + t, 1.f);
         Mt.W2 = cur;
         if (int rc = launch_forward(B, &Mt, ws, b, 1, use_bits, s, true)) return rc;
-        if (int rc = launch_fused_step(B, &Mt, ws, labels, b, use_bits, k, nxt, s, 1, nullptr, G ? &st : nullptr)) return rc;
+        if (int rc = launch_fused_step(B, &Mt, ws, labels, b, use_bits, k, nxt, s, 1, nullptr, G ? &st : nullptr, t + 1 < n ? b + 1 : -1)) return rc;
         float* tmp = cur; cur = nxt; nxt = tmp;
     }
     if (cur != M->W2) {   // odd number of steps: the current W2 lives in the scratch buffer
