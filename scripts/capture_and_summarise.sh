@@ -8,7 +8,7 @@ tags=("$@"); [ ${#tags[@]} -eq 0 ] && tags=(default fp32eval e30 w64 e30eval run
 for t in "${tags[@]}"; do
   bash scripts/capture_round4.sh $t
   case $t in
-    default) extra=(--traffic "scores_stream_kernel<16, false, 1, false, true>");;
+    default) extra=(--traffic "scores_stream_kernel<16, false, 1, false, true>" --as-default);;
     e30) extra=(--traffic "scores_stream_kernel<16, true, 3, false, false>");;
     w64) extra=(--traffic "scores_wide_ring_kernel<5, true>");;
     *) extra=();;
