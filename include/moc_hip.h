@@ -71,7 +71,12 @@ enum { MOC_STATS_COMPACT = 1,
        /* moc_meta_forward on fp32 bags, 16 rows per workgroup: keep to four waves, every wave the whole chain over the
         * columns of its hidden units (the default splits the columns over four wave groups, sixteen waves: the training
         * step's forward); the same bits -- the bit exists so that tests can say so */
-       MOC_FORWARD_FOUR_WAVES = 16 };
+       MOC_FORWARD_FOUR_WAVES = 16,
+       /* moc_meta_forward of ONE slide on 16-bit bags: keep to 16 rows per workgroup even when the slide has 16,384 or
+        * more selectable rows (the default there is the 64-row kernel: every W1 fragment feeds four row tiles -- at
+        * 25,000 rows the sixteen-row workgroups re-read 390 KB of W1 image 1,580 times); the same bits -- the bit exists
+        * so that tests can say so */
+       MOC_FORWARD_ROWS16 = 32 };
 
 /* bits of `discard_bits`, in the order of main_moc.py:341-350 */
 enum { MOC_SEL_TOPK = 1, MOC_SEL_DELTA_SOFTMAX = 2, MOC_SEL_DELTA_DIFF = 4, MOC_SEL_BOTTOMK = 8 };

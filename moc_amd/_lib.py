@@ -24,6 +24,7 @@ MOC_SELECT_PER_COLUMN = 2
 MOC_CAND_FROM_STATS = 4
 MOC_FORWARD_ROWS64 = 8
 MOC_FORWARD_FOUR_WAVES = 16
+MOC_FORWARD_ROWS16 = 32
 SEL_BITS = {"topk": 1, "delta_softmax": 2, "delta_diff": 4, "bottomk": 8}
 
 _p = C.c_void_p

@@ -2948,6 +2948,7 @@ int launch_w1_image(const moc_batch_t* B, const moc_meta_t* M, hipStream_t s) {
     return MOC_OK;
 }
 
+constexpr int F64_SINGLE_ROWS = 16384;   // one slide: the 64-row forward from this many selectable rows on (16-bit bags)
 int s_bound(const moc_batch_t* B) {
     const int64_t by_sel = (int64_t)B->topj * (2 * B->C + 2);
     return (int)(by_sel < B->max_rows ? by_sel : B->max_rows);
@@ -3046,7 +3047,11 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
         MOC_CHECK_LAUNCH("moc_meta_forward(128)");
         return MOC_OK;
     }
-    if (n >= 4 && B->dtype != MOC_F32 && (B->D * 2) % 512 == 0) {       // many slides at once (evaluation)
+    // ... or ONE slide of F64_SINGLE_ROWS or more selectable rows (the training forward of the 64-way x 50 k shape: 25,000
+    // rows were 1,580 sixteen-row workgroups, each reading the whole 390-KB W1 image: 42.7 us; 8.9 -> 10.1 k meta-steps/s.
+    // EBRAINS-30's 7,000 rows are faster sixteen at a time, and the 128-row kernel loses on one slide at either size.)
+    const bool one_big = n == 1 && s_bound(B) >= F64_SINGLE_ROWS && !a.tile_on && !(B->flags & MOC_FORWARD_ROWS16);
+    if ((n >= 4 || one_big) && B->dtype != MOC_F32 && (B->D * 2) % 512 == 0) {       // many slides at once (evaluation)
         dim3 g64(moc_cdiv(s_bound(B), 64), n);
         if (B->dtype == MOC_F16) meta_forward64_kernel<true><<<g64, 256, 0, s>>>(a);
         else meta_forward64_kernel<false><<<g64, 256, 0, s>>>(a);

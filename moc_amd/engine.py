@@ -314,7 +314,7 @@ class SlideBatch:
         cand_from_stats: an evaluation pass -- the forward reads the candidate scores from the statistics, the
         [2C+2, S] candidate columns of wide banks are never written (MOC_CAND_FROM_STATS)."""
         self.c.flags = ((_lib.MOC_STATS_COMPACT if compact else 0) | (_lib.MOC_CAND_FROM_STATS if cand_from_stats else 0) |
-                        (self.c.flags & (_lib.MOC_SELECT_PER_COLUMN | _lib.MOC_FORWARD_ROWS64 | _lib.MOC_FORWARD_FOUR_WAVES)))
+                        (self.c.flags & (_lib.MOC_SELECT_PER_COLUMN | _lib.MOC_FORWARD_ROWS64 | _lib.MOC_FORWARD_FOUR_WAVES | _lib.MOC_FORWARD_ROWS16)))
 
     def phase_a(self, bank: Bank, for_eval: bool = False):
         assert bank.D == self.D and bank.C == self.C and bank.Ce == self.Ce and bank.dtype == self.X.dtype

@@ -713,6 +713,47 @@ def test_batched_forward_is_bit_identical_to_one_slide_at_a_time(dev, dtype, D, 
         assert torch.equal(together["gates"][o:o + n], t["gates"][o:o + n])
 
 
+@pytest.mark.parametrize("dtype,D,C", [(torch.float16, 1024, 30), (torch.bfloat16, 512, 40)])
+def test_one_big_slide_takes_the_64_row_forward_with_the_16_row_bits(dev, dtype, D, C):
+    """ONE slide with 16,384 or more selectable rows (the training forward of the 64-way x 50 k shape) goes through the
+    64-row forward kernel; with MOC_FORWARD_ROWS16 it stays on the sixteen-row one: the same hidden layer, gates and
+    mixed scores, bit for bit (main_moc.py:390-403)."""
+    M, E = _mm(), _engine()
+    from moc_amd import _lib
+    j, K = 400, 10
+    W, We = synth.make_bank(73, D, C)
+    Wd, Wed = W.to(dev), We.to(dev)
+    sizes = [21000, 500]
+    bags = [synth.make_bag_device(7300 + i, n, D, We, C, i % C, dev, dtype) for i, n in enumerate(sizes)]
+    torch.manual_seed(5)
+    model = M.senet(D, 4).to(dev)
+    X, _ = M._pack(bags, dev, dtype)
+    out = {}
+    for rows16 in (False, True):
+        b = E.SlideBatch(X, sizes, C, C + 4, j, K)
+        b.c.flags = _lib.MOC_FORWARD_ROWS16 if rows16 else 0
+        b.phase_a(E.Bank.get(Wd, Wed, dtype, dev))
+        assert bool(b.c.flags & _lib.MOC_FORWARD_ROWS16) == rows16
+        assert min(j * (2 * C + 2), b.c.max_rows) >= 16384           # (the bound the launcher looks at)
+        meta = E.MetaState(model)
+        t = b.meta_ws()[0]
+        for k in ("mixed", "H1", "gates"):
+            t[k].zero_()
+        E.meta_forward(b, meta, 0, 1, 15)
+        E.meta_forward(b, meta, 1, 1, 15)
+        torch.cuda.synchronize()
+        n0 = int(b.n_sel.cpu()[0])
+        assert n0 > 4096
+        out[rows16] = ({k: t[k].clone() for k in ("mixed", "H1", "gates")}, b.n_sel.cpu().tolist(), list(b.row_off_host[:2]))
+    (a, ns, off), (c, ns2, off2) = out[False], out[True]
+    assert ns == ns2 and off == off2
+    for i, n in enumerate(ns):
+        o = off[i]
+        assert torch.equal(a["mixed"][:, o:o + n], c["mixed"][:, o:o + n])
+        assert torch.equal(a["H1"][o:o + n], c["H1"][o:o + n])
+        assert torch.equal(a["gates"][o:o + n], c["gates"][o:o + n])
+
+
 @pytest.mark.parametrize("D,C,j,for_eval", [(512, 2, 400, False), (256, 3, 150, False), (768, 5, 90, False), (1024, 30, 40, False),
                                             (512, 64, 20, False), (512, 30, 60, True), (256, 6, 100, True)])
 def test_fp32_forward_split_over_four_wave_groups_gives_the_four_wave_bits(dev, D, C, j, for_eval):
