@@ -297,9 +297,14 @@ typedef struct moc_runs {
     int64_t par_stride;    /* floats */
     int64_t image_stride;  /* bytes, >= moc_w1_image_bytes(D, dtype) */
 } moc_runs_t;
-/* M: run 0's tensors.  ws->W2_alt: [n_runs, 4, H].  ws->tile_ws required (the tile-record step is the only one batched). */
+/* M: run 0's tensors.  ws->W2_alt: [n_runs, 4, H].  With ws->tile_ws and a shape of the tile-record step (C <= 16, K <= 16,
+ * C K <= 64, <= 4,096 selectable rows) the runs step in lockstep (moc_train_runs_mode == 1); other shapes of the one-launch
+ * steps (wide banks: EBRAINS-30, the 64-way shape) take every run's pass one after the other on `stream`, with the launches
+ * of moc_train_steps (mode 2: give every run a call and a stream of its own to have their chains side by side); shapes of
+ * the three-launch step are refused (mode 0: its scratch is one per batch). */
 int moc_train_steps_runs(const moc_batch_t* B, const moc_meta_t* M, const moc_runs_t* R, const moc_meta_ws_t* ws,
                          const int64_t* labels, int slide0, int n, uint32_t use_bits, moc_stream_t stream);
+int moc_train_runs_mode(const moc_batch_t* B, const moc_meta_ws_t* ws);
 
 /* a10-a14 for ONE slide without the update: forward, pooling, loss (ws->loss/pooled/pred) and
  * the gradients of that loss w.r.t. the four parameter tensors, written (not accumulated) to

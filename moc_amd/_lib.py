@@ -90,6 +90,7 @@ SIGNATURES = {
     "moc_adam_step": (C.c_int, [_MP, C.c_float, _p]),
     "moc_train_steps": (C.c_int, [_BP, _MP, _WP, _p, C.c_int, C.c_int, C.c_uint32, _p]),
     "moc_train_steps_runs": (C.c_int, [_BP, _MP, C.POINTER(MocRuns), _WP, _p, C.c_int, C.c_int, C.c_uint32, _p]),
+    "moc_train_runs_mode": (C.c_int, [_BP, _WP]),
     "moc_step_graph_workspace_bytes": (C.c_size_t, [C.c_int]),
     "moc_step_graph_create": (C.c_int, [_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "moc_step_graph_destroy": (C.c_int, [_p]),

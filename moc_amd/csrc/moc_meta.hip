@@ -3603,6 +3603,12 @@ extern "C" int moc_train_steps(const moc_batch_t* B, const moc_meta_t* M, const 
 // one run is a chain of dependent 17-us steps that leaves most of the GPU idle.  Here ONE forward launch and ONE step
 // launch serve R runs: grid.y / grid.z = run.  Every run stays the exact recurrence of moc_train_steps -- its own slides,
 // parameters, Adam moments; the same kernels, the same operation order: bit-identical to running it alone.
+extern "C" int moc_train_runs_mode(const moc_batch_t* B, const moc_meta_ws_t* ws) {
+    if (!B || !ws) return 0;
+    if (tiles_ok(B, ws)) return 1;
+    return fused_step_mode(B, ws) != 0 ? 2 : 0;
+}
+
 extern "C" int moc_train_steps_runs(const moc_batch_t* B, const moc_meta_t* M, const moc_runs_t* R, const moc_meta_ws_t* ws,
                                     const int64_t* labels, int slide0, int n, uint32_t use_bits, moc_stream_t stream) {
     if (int rc = moc_check_batch(B, "moc_train_steps_runs")) return rc;
@@ -3612,9 +3618,29 @@ extern "C" int moc_train_steps_runs(const moc_batch_t* B, const moc_meta_t* M, c
                 slide0 + n + (R->n_runs - 1) * R->slide_stride <= B->n_slides, "moc_train_steps_runs: bad labels/slide range");
     MOC_REQUIRE(R->par_stride >= (int64_t)H * B->D + H + 4 * H + 4 && R->image_stride >= (int64_t)moc_w1_image_bytes(B->D, B->dtype),
                 "moc_train_steps_runs: parameter / image stride smaller than one meta-learner");
-    MOC_REQUIRE(tiles_ok(B, ws), "moc_train_steps_runs: shape outside the tile-record step (C <= 16, K <= 16, C*K <= 64, selected rows <= 4096, "
-                                 "D <= 1024, ws->tile_ws and W2_alt set)");
     hipStream_t s = (hipStream_t)stream;
+    if (!tiles_ok(B, ws)) {
+        // Shapes outside the tile-record step (wide banks: EBRAINS-30, the 64-way shape; C > 16, C K > 64, more than 4,096
+        // selectable rows): every run's pass through moc_train_steps' own launches, one run after the other on this stream --
+        // the same kernels on the same tensors as the run alone, so the same bits.  What the caller still gains is phase A
+        // over all runs' slides in one pass and (moc_amd.runs: one group per run) the runs' chains side by side on streams
+        // of their own, each of which keeps a few dozen CUs busy.  The one-launch steps only (W2_alt set): the three-launch
+        // step's scratch is one per batch.
+        MOC_REQUIRE(fused_step_mode(B, ws) != 0, "moc_train_steps_runs: this shape needs ws->W2_alt (the one-launch steps)");
+        for (int r = 0; r < R->n_runs; ++r) {
+            moc_meta_t Mr = *M;
+            const int64_t po = (int64_t)r * R->par_stride;
+            Mr.W1 += po; Mr.b1 += po; Mr.W2 += po; Mr.b2 += po;
+            Mr.m_W1 += po; Mr.m_b1 += po; Mr.m_W2 += po; Mr.m_b2 += po;
+            Mr.v_W1 += po; Mr.v_b1 += po; Mr.v_W2 += po; Mr.v_b2 += po;
+            Mr.g_W1 = Mr.g_b1 = Mr.g_W2 = Mr.g_b2 = nullptr;
+            Mr.W1_image = (unsigned char*)M->W1_image + (int64_t)r * R->image_stride;
+            moc_meta_ws_t wr = *ws;
+            wr.W2_alt = ws->W2_alt + (int64_t)r * 4 * H;
+            if (int rc = issue_fused_pass(B, &Mr, &wr, labels, slide0 + r * R->slide_stride, n, use_bits, s, nullptr)) return rc;
+        }
+        return MOC_OK;
+    }
     fused_step_attrs();
     w1_image_kernel<<<dim3(H * B->D / 256, R->n_runs), 256, 0, s>>>(M->W1, B->D, (unsigned char*)M->W1_image, B->dtype, R->par_stride,
                                                                     R->image_stride);

@@ -136,7 +136,13 @@ class TrainRuns:
         self.last = None
         # The runs step in lockstep inside a GROUP; several groups are independent chains on streams of their own, whose
         # latency-bound kernels interleave on the device (one group: every launch serves all R runs)
-        G = max(1, min(R, int(os.environ.get("MOC_RUNS_GROUPS", str((R + 7) // 8)))))     # (measured: chains of up to eight runs)
+        # Shapes outside the tile-record step (wide banks): moc_train_steps_runs takes a group's runs one after the other,
+        # so every run is a group of its own -- R chains of (forward, top-K, wide step) side by side, each of which keeps
+        # a few dozen CUs busy (include/moc_hip.h moc_train_runs_mode)
+        self.mode = int(lib().moc_train_runs_mode(C.byref(self.batches[0].c), C.byref(self.batches[0].meta_ws()[1])))
+        assert self.mode != 0, "train_runs: this shape takes the three-launch step, whose scratch is one per batch -- train the runs one by one"
+        G_default = (R + 7) // 8 if self.mode == 1 else R
+        G = max(1, min(R, int(os.environ.get("MOC_RUNS_GROUPS", str(G_default)))))        # (measured, lockstep: chains of up to eight runs)
         per = (R + G - 1) // G
         self.groups = []
         for r0 in range(0, R, per):
@@ -227,23 +233,37 @@ class TrainRuns:
             ready = torch.cuda.Event()
             ready.record(main)                               # phase A of this pass is in front of it on the main stream
         joins = []
-        for grp in self.groups:
+
+        def group_call(grp, raw_stream):
             ws = type(ws0).from_buffer_copy(ws0)
             ws.W2_alt = grp["w2alt"]
             mc = grp["meta"]
             mc.lr, mc.beta1, mc.beta2, mc.eps, mc.weight_decay, mc.step = (self.meta.c.lr, self.meta.c.beta1, self.meta.c.beta2,
                                                                             self.meta.c.eps, self.meta.c.weight_decay, self.meta.c.step)
-            if grp["stream"] is None:
-                check(lib().moc_train_steps_runs(C.byref(batch.c), C.byref(mc), C.byref(grp["runs"]), C.byref(ws), ptr(self.labels),
-                                                 grp["r0"] * self.n, self.n, use, engine._stream()), "moc_train_steps_runs")
-            else:
+            return lib().moc_train_steps_runs(C.byref(batch.c), C.byref(mc), C.byref(grp["runs"]), C.byref(ws), ptr(self.labels),
+                                              grp["r0"] * self.n, self.n, use, raw_stream)
+        main_raw = engine._stream()
+        raw_of = lambda grp: main_raw if grp["stream"] is None else C.c_void_p(grp["stream"].cuda_stream)
+        for grp in self.groups:
+            if grp["stream"] is not None:
                 grp["stream"].wait_event(ready)
-                with torch.cuda.stream(grp["stream"]):
-                    check(lib().moc_train_steps_runs(C.byref(batch.c), C.byref(mc), C.byref(grp["runs"]), C.byref(ws), ptr(self.labels),
-                                                     grp["r0"] * self.n, self.n, use, engine._stream()), "moc_train_steps_runs")
-                    ev = torch.cuda.Event()
-                    ev.record(grp["stream"])
-                    joins.append(ev)
+        if self.mode == 2 and len(self.groups) > 1:
+            # one chain of three launches per meta-step and run: the host's launch calls are what would hold the chains apart
+            # (120 steps x 3 launches x ~4 us per run and pass), so every group's pass is issued from a thread of its own (the
+            # library call releases the GIL; the stream is handed over as its raw handle)
+            def threaded(grp):
+                torch.cuda.set_device(self.device)             # (a new thread's current device is device 0)
+                return group_call(grp, raw_of(grp))
+            rcs = list(self.pool.map(threaded, self.groups))
+        else:
+            rcs = [group_call(grp, raw_of(grp)) for grp in self.groups]
+        for rc in rcs:
+            check(rc, "moc_train_steps_runs")
+        for grp in self.groups:
+            if grp["stream"] is not None:
+                ev = torch.cuda.Event()
+                ev.record(grp["stream"])
+                joins.append(ev)
         for ev in joins:
             main.wait_event(ev)
         for opt in self.optimizers:                           # n fused Adam steps in every optimizer's own counters
