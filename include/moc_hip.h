@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 16
+#define MOC_ABI_VERSION 17
 
 enum { MOC_TICKET_QUEUES = 64, MOC_TICKET_STRIDE = 64,     /* moc_batch_t.tile_ticket: counters, int32 words between them */
        MOC_TICKET_WORDS = (64 + 8) * 64 };

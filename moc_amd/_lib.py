@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 MOC_F32, MOC_BF16, MOC_F16 = 0, 1, 2
 TICKET_WORDS = (64 + 8) * 64    # MOC_TICKET_WORDS (moc_batch_t.tile_ticket)
