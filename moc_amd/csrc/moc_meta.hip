@@ -1852,11 +1852,13 @@ struct TileStepArgs {
     int64_t par_stride, w2_stride, w2out_stride, img_stride;
     int64_t base_r[MOC_MAX_RUNS], slot0_r[MOC_MAX_RUNS];
     int32_t cap_r[MOC_MAX_RUNS], ntb_r[MOC_MAX_RUNS];
-    // ---- the slide the NEXT step works on (same work arrays; -1: none): its selected rows are pulled toward the Infinity
-    // Cache by the waves that have no class to pool (runs: the slide after each run's own, when next_base >= 0)
-    int64_t next_base;
-    int sink_off, pad1_;            // byte offset of 1 KiB of LDS nobody reads (the prefetch's LDS-DMA destination)
-    int64_t next_base_r[MOC_MAX_RUNS];
+    // ---- the slide the NEXT step works on (slide b + 1 of the same work arrays): its selected rows are pulled toward the
+    // Infinity Cache by the waves that have no class to pool
+    // (the slide's first slot is read from the device's row_off by the prefetching waves themselves: a per-run array of them
+    // made the argument segment 984 bytes, and the two more lines of it cost every launch 0.25 us)
+    const int64_t* row_off;
+    int prefetch_next;              // != 0: slide b + 1 follows in the same work arrays
+    int sink_off;                   // byte offset of 1 KiB of LDS nobody reads (the prefetch's LDS-DMA destination)
 };
 static_assert(sizeof(TileStepArgs) <= 1024, "a kernel-argument segment over 1 KiB takes a slow launch path (profiles/NOTES.md)");
 
@@ -1949,9 +1951,8 @@ __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs
     // from the pass before (a 1-GB copy between two passes of steps with nothing else on the GPU: 16.8 -> 18.5 us per
     // step, scripts/diag_mall.py).  Inline asm: the compiler's wait insertion does not see these loads, nobody waits for
     // them (s_endpgm does).
-    if (wave >= C && a.next_base >= 0) {
-        int64_t nb = a.next_base;
-        if (runs) nb = kernarg_at<int64_t>(offsetof(TileStepArgs, next_base_r) + 8 * (size_t)blockIdx.z);
+    if (wave >= C && a.prefetch_next) {
+        const int64_t nb = a.row_off[b + 1];
         const int S2 = a.n_sel[b + 1];
         const int esz_p = a.xdt == MOC_F32 ? 4 : 2;
         const int lpr = D * esz_p / 128;                                            // lines per row
@@ -3271,7 +3272,7 @@ TileStepArgs tile_step_args(const moc_batch_t* B, const moc_meta_t* M, const moc
     ta.b1 = M->b1; ta.m_b1 = M->m_b1; ta.v_b1 = M->v_b1; ta.b2 = M->b2; ta.m_b2 = M->m_b2; ta.v_b2 = M->v_b2;
     ta.m_W2 = M->m_W2; ta.v_W2 = M->v_W2;
     ta.base = B->row_off_host[slide]; ta.adam = k;
-    ta.next_base = -1;
+    ta.row_off = B->row_off; ta.prefetch_next = 0;
     ta.sink_off = (int)(tiles_step_smem(B, ta.PS_CAP) - TILES_SINK);
     if (tab) { ta.adam_tab = tab->tab; ta.adam_ctr = tab->ctr; ta.adam_pos = tab->pos; }
     ta.apply_adam = apply_adam; ta.use_bits = use_bits; ta.img_dt = B->dtype;
@@ -3352,7 +3353,7 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
         fused_step_attrs();
         TileStepArgs ta = tile_step_args(B, M, ws, labels, slide, use_bits, k, W2out, apply_adam, tab);
         static const bool prefetch = !(getenv("MOC_STEP_PREFETCH") && atoi(getenv("MOC_STEP_PREFETCH")) == 0);   // diagnostic: off
-        if (prefetch && next_slide >= 0 && next_slide < B->n_slides && B->C < 4) ta.next_base = B->row_off_host[next_slide];
+        if (prefetch && next_slide == slide + 1 && next_slide < B->n_slides && B->C < 4) ta.prefetch_next = 1;
         return launch_tile_step(B, ta, 1, s);
     }
     const size_t smem = fused_step_smem(B, cap);
@@ -3663,11 +3664,10 @@ extern "C" int moc_train_steps_runs(const moc_batch_t* B, const moc_meta_t* M, c
         static const bool prefetch = !(getenv("MOC_STEP_PREFETCH") && atoi(getenv("MOC_STEP_PREFETCH")) == 0);   // diagnostic: off
         // (launches of four runs or more are bound by workgroup slots, not by one run's latency: the prefetch cost eight
         // batched runs 3.6 %)
-        if (prefetch && t + 1 < n && B->C < 4 && R->n_runs < 4) ta.next_base = 0;     // (any value >= 0: the runs' own are in next_base_r)
+        if (prefetch && t + 1 < n && B->C < 4 && R->n_runs < 4) ta.prefetch_next = 1;
         for (int r = 0; r < R->n_runs; ++r) {
             const int sl = b + r * R->slide_stride;
             ta.base_r[r] = B->row_off_host[sl];
-            ta.next_base_r[r] = t + 1 < n ? B->row_off_host[sl + 1] : -1;
             int cap_, tb_;
             tile_region(B, sl, &ta.slot0_r[r], &cap_, &tb_);
             ta.cap_r[r] = cap_; ta.ntb_r[r] = tb_;
