@@ -1850,8 +1850,6 @@ struct TileStepArgs {
     // ---- batched runs (n_runs > 0): grid.z = run; run r steps the meta-learner whose tensors lie par_stride floats (W2 in:
     // w2_stride, W2 out: w2out_stride, operand image: img_stride bytes) behind run 0's, on slide slide0 + r * slide_stride
     int64_t par_stride, w2_stride, w2out_stride, img_stride;
-    int64_t base_r[MOC_MAX_RUNS], slot0_r[MOC_MAX_RUNS];
-    int32_t cap_r[MOC_MAX_RUNS], ntb_r[MOC_MAX_RUNS];
     // ---- the slide the NEXT step works on (slide b + 1 of the same work arrays): its selected rows are pulled toward the
     // Infinity Cache by the waves that have no class to pool
     // (the slide's first slot is read from the device's row_off by the prefetching waves themselves: a per-run array of them
@@ -1860,24 +1858,36 @@ struct TileStepArgs {
     int prefetch_next;              // != 0: slide b + 1 follows in the same work arrays
     int sink_off;                   // byte offset of 1 KiB of LDS nobody reads (the prefetch's LDS-DMA destination)
 };
-static_assert(sizeof(TileStepArgs) <= 1024, "a kernel-argument segment over 1 KiB takes a slow launch path (profiles/NOTES.md)");
+// The launch of batched runs carries the per-run scalars behind the common block; ONE run's launch does not: the argument
+// segment lives in host memory and every 64-byte line of it that the kernel touches costs its start ~0.1 us (984 -> 864
+// bytes: alone 16.70 -> 16.45 us per step; without the 384 bytes of per-run arrays: see profiles/NOTES.md).
+struct TileStepArgsRuns {
+    TileStepArgs s;
+    int64_t base_r[MOC_MAX_RUNS], slot0_r[MOC_MAX_RUNS];
+    int32_t cap_r[MOC_MAX_RUNS], ntb_r[MOC_MAX_RUNS];
+};
+static_assert(sizeof(TileStepArgsRuns) <= 1024, "a kernel-argument segment over 1 KiB takes a slow launch path (profiles/NOTES.md)");
+__host__ __device__ __forceinline__ const TileStepArgs& tile_common(const TileStepArgs& x) { return x; }
+__host__ __device__ __forceinline__ const TileStepArgs& tile_common(const TileStepArgsRuns& x) { return x.s; }
 
-template <int VQ>
-__global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs a) {
+template <int VQ, typename ArgsT>
+__global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(ArgsT args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool RUNS = std::is_same<ArgsT, TileStepArgsRuns>::value;
+    const TileStepArgs& a = tile_common(args);
     static_assert(offsetof(TileStepArgs, n_sel) + 8 <= 64, "the first loads' arguments must share the first cache line");
     // batched runs: this workgroup's run -- its slide, its region of the records, the offsets of its tensors (the argument
     // block itself is not modified and its arrays are read through kernarg_at: either would send all of it to scratch)
     int b = a.slide0;
     int64_t base = 0, slot0 = a.slot0, po = 0, w2o = 0, w2outo = 0, imgo = 0;
     int cap = a.cap, ntile_bound = a.ntile_bound;
-    const bool runs = a.n_runs > 0;
-    if (runs) {
+    constexpr bool runs = RUNS;
+    if constexpr (RUNS) {
         const int run = blockIdx.z;
         b += run * a.slide_stride;
-        slot0 = kernarg_at<int64_t>(offsetof(TileStepArgs, slot0_r) + 8 * (size_t)run);
-        cap = kernarg_at<int32_t>(offsetof(TileStepArgs, cap_r) + 4 * (size_t)run);
-        ntile_bound = kernarg_at<int32_t>(offsetof(TileStepArgs, ntb_r) + 4 * (size_t)run);
+        slot0 = kernarg_at<int64_t>(offsetof(TileStepArgsRuns, slot0_r) + 8 * (size_t)run);
+        cap = kernarg_at<int32_t>(offsetof(TileStepArgsRuns, cap_r) + 4 * (size_t)run);
+        ntile_bound = kernarg_at<int32_t>(offsetof(TileStepArgsRuns, ntb_r) + 4 * (size_t)run);
     }
     const int C = a.C, K = a.K, D = a.D;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1913,12 +1923,12 @@ __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(TileStepArgs
     }
     if (wave < C) MOC_TILE_KEYS(wave)
     __builtin_amdgcn_sched_barrier(0);
-    moc_kernarg_touch<sizeof(TileStepArgs)>();           // every other line of the arguments, side by side, one wait
+    moc_kernarg_touch<sizeof(ArgsT)>();                  // every other line of the arguments, side by side, one wait
     const int PS_CAP = a.PS_CAP;
     base = a.base;
-    if (runs) {
+    if constexpr (RUNS) {
         const int run = blockIdx.z;
-        base = kernarg_at<int64_t>(offsetof(TileStepArgs, base_r) + 8 * (size_t)run);
+        base = kernarg_at<int64_t>(offsetof(TileStepArgsRuns, base_r) + 8 * (size_t)run);
         po = (int64_t)run * a.par_stride; w2o = (int64_t)run * a.w2_stride; w2outo = (int64_t)run * a.w2out_stride;
         imgo = (int64_t)run * a.img_stride;
     }
@@ -3242,10 +3252,11 @@ void fused_step_attrs() {
     if (done) return;
     (void)hipFuncSetAttribute((const void*)pool_w1_step_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
     (void)hipFuncSetAttribute((const void*)pool_w1_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
-    (void)hipFuncSetAttribute((const void*)pool_w1_step_tiles_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
-    (void)hipFuncSetAttribute((const void*)pool_w1_step_tiles_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
-    (void)hipFuncSetAttribute((const void*)pool_w1_step_tiles_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
-    (void)hipFuncSetAttribute((const void*)pool_w1_step_tiles_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS);
+#define MOC_TILES_ATTR(VQ)                                                                                                         \
+    (void)hipFuncSetAttribute((const void*)pool_w1_step_tiles_kernel<VQ, TileStepArgs>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS); \
+    (void)hipFuncSetAttribute((const void*)pool_w1_step_tiles_kernel<VQ, TileStepArgsRuns>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_DYN_LDS)
+    MOC_TILES_ATTR(4); MOC_TILES_ATTR(8); MOC_TILES_ATTR(12); MOC_TILES_ATTR(16);
+#undef MOC_TILES_ATTR
     done = true;
 }
 
@@ -3285,13 +3296,14 @@ TileStepArgs tile_step_args(const moc_batch_t* B, const moc_meta_t* M, const moc
     return ta;
 }
 
-// launches it for `runs` meta-learners (grid.z); the largest tile bound of any run picks the keys per lane
-int launch_tile_step(const moc_batch_t* B, const TileStepArgs& ta, int runs, hipStream_t s) {
+// launches it -- for ONE meta-learner (the common argument block alone) or for tr.s.n_runs of them (grid.z; the per-run
+// scalars behind the common block); the largest tile bound of any run picks the keys per lane
+template <typename ArgsT>
+int launch_tile_step_as(const moc_batch_t* B, const ArgsT& args, int runs, int tb, hipStream_t s) {
+    const TileStepArgs& ta = tile_common(args);
     const size_t sm = tiles_step_smem(B, ta.PS_CAP);
     const dim3 grid(B->D / 256 + (ta.tail_inside ? 0 : 1), H, runs);   // D / 256 column blocks of W1 (+ the tail workgroup), per hidden unit
-    int tb = ta.ntile_bound;
-    for (int r = 0; r < ta.n_runs; ++r) tb = ta.ntb_r[r] > tb ? ta.ntb_r[r] : tb;
-#define MOC_TILES_LAUNCH(VQ) pool_w1_step_tiles_kernel<VQ><<<grid, 256, sm, s>>>(ta)
+#define MOC_TILES_LAUNCH(VQ) pool_w1_step_tiles_kernel<VQ, ArgsT><<<grid, 256, sm, s>>>(args)
     const int vq = moc_cdiv((int64_t)tb * TILE_R, 64);                 // keys per lane of a class wave
     if (vq <= 4) MOC_TILES_LAUNCH(4);
     else if (vq <= 8) MOC_TILES_LAUNCH(8);
@@ -3300,6 +3312,14 @@ int launch_tile_step(const moc_batch_t* B, const TileStepArgs& ta, int runs, hip
 #undef MOC_TILES_LAUNCH
     MOC_CHECK_LAUNCH("moc_fused_step(tiles)");
     return MOC_OK;
+}
+int launch_tile_step(const moc_batch_t* B, const TileStepArgs& ta, hipStream_t s) {
+    return launch_tile_step_as(B, ta, 1, ta.ntile_bound, s);
+}
+int launch_tile_step_runs(const moc_batch_t* B, const TileStepArgsRuns& tr, hipStream_t s) {
+    int tb = tr.s.ntile_bound;
+    for (int r = 0; r < tr.s.n_runs; ++r) tb = tr.ntb_r[r] > tb ? tr.ntb_r[r] : tb;
+    return launch_tile_step_as(B, tr, tr.s.n_runs, tb, s);
 }
 
 // next_slide: the slide the step after this one works on, in the same work arrays (-1: none / unknown) -- the tile-record
@@ -3354,7 +3374,7 @@ int launch_fused_step(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_
         TileStepArgs ta = tile_step_args(B, M, ws, labels, slide, use_bits, k, W2out, apply_adam, tab);
         static const bool prefetch = !(getenv("MOC_STEP_PREFETCH") && atoi(getenv("MOC_STEP_PREFETCH")) == 0);   // diagnostic: off
         if (prefetch && next_slide == slide + 1 && next_slide < B->n_slides && B->C < 4) ta.prefetch_next = 1;
-        return launch_tile_step(B, ta, 1, s);
+        return launch_tile_step(B, ta, s);
     }
     const size_t smem = fused_step_smem(B, cap);
     static bool attr_set = false;
@@ -3655,7 +3675,9 @@ extern "C" int moc_train_steps_runs(const moc_batch_t* B, const moc_meta_t* M, c
         const AdamCoef k = adam_coef(M, M->step + 1 + t, 1.f);
         Mt.W2 = cur;
         if (int rc = launch_forward(B, &Mt, ws, b, 1, use_bits, s, true, R, cur_stride)) return rc;
-        TileStepArgs ta = tile_step_args(B, &Mt, ws, labels, b, use_bits, k, nxt, 1, nullptr);
+        TileStepArgsRuns tr;
+        tr.s = tile_step_args(B, &Mt, ws, labels, b, use_bits, k, nxt, 1, nullptr);
+        TileStepArgs& ta = tr.s;
         ta.n_runs = R->n_runs; ta.slide_stride = R->slide_stride;
         // four runs or more: throughput, not one run's latency, is what a launch is about -- no tail workgroups
         static const int tail_env = getenv("MOC_RUNS_TAIL_INSIDE") ? atoi(getenv("MOC_RUNS_TAIL_INSIDE")) : -1;   // diagnostic override
@@ -3667,12 +3689,13 @@ extern "C" int moc_train_steps_runs(const moc_batch_t* B, const moc_meta_t* M, c
         if (prefetch && t + 1 < n && B->C < 4 && R->n_runs < 4) ta.prefetch_next = 1;
         for (int r = 0; r < R->n_runs; ++r) {
             const int sl = b + r * R->slide_stride;
-            ta.base_r[r] = B->row_off_host[sl];
+            tr.base_r[r] = B->row_off_host[sl];
             int cap_, tb_;
-            tile_region(B, sl, &ta.slot0_r[r], &cap_, &tb_);
-            ta.cap_r[r] = cap_; ta.ntb_r[r] = tb_;
+            tile_region(B, sl, &tr.slot0_r[r], &cap_, &tb_);
+            tr.cap_r[r] = cap_; tr.ntb_r[r] = tb_;
         }
-        if (int rc = launch_tile_step(B, ta, R->n_runs, s)) return rc;
+        for (int r = R->n_runs; r < MOC_MAX_RUNS; ++r) { tr.base_r[r] = 0; tr.slot0_r[r] = 0; tr.cap_r[r] = 0; tr.ntb_r[r] = 0; }
+        if (int rc = launch_tile_step_runs(B, tr, s)) return rc;
         float* tmp = cur; cur = nxt; nxt = tmp;
         const int64_t ts = cur_stride; cur_stride = nxt_stride; nxt_stride = ts;
     }
