@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MOC_ABI_VERSION 17
+#define MOC_ABI_VERSION 18
 
 enum { MOC_TICKET_QUEUES = 64, MOC_TICKET_STRIDE = 64,     /* moc_batch_t.tile_ticket: counters, int32 words between them */
        MOC_TICKET_WORDS = (64 + 8) * 64 };
@@ -129,6 +129,12 @@ typedef struct moc_batch {
     /* ---- placement of the score pass (round 3; both nullable = static walk over the whole chip) ---- */
     const uint32_t* cu_reserved; /* device [128]: compute units the score pass stays off (see moc_cu_census)   */
     int32_t*        tile_ticket; /* device [MOC_TICKET_WORDS]: the score pass's tile counters                  */
+    /* ---- round 4, second session (nullable) ---- */
+    const int32_t*  n_sel_host;  /* HOST [n_slides]: a copy of n_sel that the caller has seen arrive (e.g. an asynchronous
+                                    copy behind phase A whose event has completed), or NULL.  The train steps then take
+                                    a slide's S as a kernel argument instead of loading it -- one dependent round trip
+                                    less at the head of the forward (arguments -> sel_row -> rows), exact grids, fewer
+                                    record keys per lane in the step.  The same results either way.                   */
 } moc_batch_t;
 
 /* The meta-learner ("senet", main_moc.py:299-312) and its Adam state

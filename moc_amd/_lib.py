@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOC_HIP_LIB") or os.path.join(_HERE, "libmoc_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 MOC_F32, MOC_BF16, MOC_F16 = 0, 1, 2
 TICKET_WORDS = (64 + 8) * 64    # MOC_TICKET_WORDS (moc_batch_t.tile_ticket)
@@ -38,7 +38,7 @@ class MocBatch(C.Structure):
         ("discard_bits", C.c_uint32), ("flags", C.c_uint32),
         ("kept", _p), ("n_kept", _p), ("stats", _p), ("sel_flag", _p), ("sel_idx", _p),
         ("sel_row", _p), ("n_sel", _p), ("cand", _p),
-        ("cu_reserved", _p), ("tile_ticket", _p),
+        ("cu_reserved", _p), ("tile_ticket", _p), ("n_sel_host", _p),
     ]
 
 

@@ -149,6 +149,10 @@ struct FwdArgs {
     int64_t par_stride, w2_stride, img_stride;
     int64_t base_r[MOC_MAX_RUNS], tile_slot0_r[MOC_MAX_RUNS];
     int32_t tile_cap_r[MOC_MAX_RUNS];
+    // the slide's selected-row count S when the HOST knows it (moc_batch_t.n_sel_host; -1: load n_sel[b]): arguments -> sel_row
+    // -> rows is one dependent round trip less than arguments -> n_sel -> sel_row -> rows.  Runs: S_r[run] (S_host >= 0 says so).
+    int S_host;
+    int32_t S_r[MOC_MAX_RUNS];
 };
 
 // An entry of an array inside the kernel's (single, by-value) argument struct, read straight from the kernel-argument
@@ -166,7 +170,7 @@ __device__ __forceinline__ T kernarg_at(size_t off) {
 
 // what a forward workgroup works on: its slide and, with batched runs, its run's tensors (the argument block is not modified)
 struct FwdRun {
-    int b;
+    int b, S;                      // S: the host-known row count, or -1
     int64_t base, tile_slot0;
     int tile_cap;
     const unsigned char* W1img;
@@ -175,8 +179,10 @@ struct FwdRun {
 __device__ __forceinline__ FwdRun fwd_run_setup(const FwdArgs& a) {
     FwdRun r;
     r.W1img = a.W1img; r.W2 = a.W2; r.b1 = a.b1; r.b2 = a.b2; r.tile_slot0 = a.tile_slot0; r.tile_cap = a.tile_cap;
+    r.S = a.S_host;
     if (a.n_runs > 0) {
         const int run = blockIdx.y;
+        if (a.S_host >= 0) r.S = kernarg_at<int32_t>(offsetof(FwdArgs, S_r) + 4 * (size_t)run);
         r.b = a.slide0 + run * a.slide_stride;
         r.base = kernarg_at<int64_t>(offsetof(FwdArgs, base_r) + 8 * (size_t)run);
         r.tile_slot0 = kernarg_at<int64_t>(offsetof(FwdArgs, tile_slot0_r) + 8 * (size_t)run);
@@ -281,10 +287,11 @@ __global__ __launch_bounds__(256) void meta_forward_kernel(FwdArgs a) {
         fr.b = a.slide0 + blockIdx.y;
         fr.base = a.base_host >= 0 ? a.base_host : a.row_off[fr.b];
         fr.W1img = a.W1img; fr.W2 = a.W2; fr.b1 = a.b1; fr.b2 = a.b2; fr.tile_slot0 = 0; fr.tile_cap = 0;
+        fr.S = a.S_host;
     }
     const int b = fr.b;
     const int64_t base = fr.base;
-    const int S = a.n_sel[b];
+    const int S = fr.S >= 0 ? fr.S : a.n_sel[b];            // (host-known: one dependent load less in front of the rows)
     const int row0 = blockIdx.x * 16;
     if (row0 >= S) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(1024) void meta_forward_ksplit_kernel(FwdArgs a) {
     const FwdRun fr = fwd_run_setup(a);
     const int b = fr.b;
     const int64_t base = fr.base;
-    const int S = a.n_sel[b];
+    const int S = fr.S >= 0 ? fr.S : a.n_sel[b];            // (host-known: one dependent load less in front of the rows)
     const int row0 = blockIdx.x * 16;
     if (row0 >= S) return;
     const int t = threadIdx.x, lane = t & 63;
@@ -2977,6 +2984,7 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
     a.tile_on = 0; a.tile_cap = 0; a.tile_slot0 = 0;
     a.tile = TileWs();
     a.n_runs = 0; a.slide_stride = 0; a.par_stride = a.w2_stride = a.img_stride = 0;
+    a.S_host = -1;
     a.X = (const unsigned char*)B->X; a.row_off = B->row_off; a.sel_row = B->sel_row; a.n_sel = B->n_sel;
     a.cand = B->cand; a.W1 = M->W1; a.b1 = M->b1; a.W2 = M->W2; a.b2 = M->b2;
     a.W1img = (const unsigned char*)M->W1_image;
@@ -2999,16 +3007,31 @@ int launch_forward(const moc_batch_t* B, const moc_meta_t* M, const moc_meta_ws_
         a.stats = B->stats; a.sel_idx = B->sel_idx;
     }
     dim3 grid(moc_cdiv(s_bound(B), 16), n);
+    // one slide (a training step) whose S the host knows: S as an argument, and exactly the workgroups that have rows
+    const bool s_known = n == 1 && B->n_sel_host != nullptr;
+    if (s_known && !runs) {
+        a.S_host = B->n_sel_host[slide0];
+        MOC_REQUIRE(a.S_host >= 0 && a.S_host <= s_bound(B), "moc_meta_forward: n_sel_host[%d] = %d is not a row count of this batch (bound %d)",
+                    slide0, a.S_host, s_bound(B));
+        grid.x = a.S_host > 0 ? moc_cdiv(a.S_host, 16) : 1;
+    }
     if (runs) {                                            // one training slide per run, grid.y = run
         MOC_REQUIRE(n == 1 && a.tile_on, "moc_train_steps_runs: the batched forward needs the tile-record step");
         a.n_runs = runs->n_runs; a.slide_stride = runs->slide_stride;
         a.par_stride = runs->par_stride; a.img_stride = runs->image_stride; a.w2_stride = w2_stride;
+        int s_max = 0;
         for (int r = 0; r < runs->n_runs; ++r) {
             const int sl = slide0 + r * runs->slide_stride;
             a.base_r[r] = B->row_off_host[sl];
             a.tile_cap_r[r] = moc_cdiv(B->row_off_host[sl + 1] - B->row_off_host[sl], 16);
             a.tile_slot0_r[r] = ((B->row_off_host[sl] >> 4) + sl) * (int64_t)B->C * TILE_R;
+            if (s_known) {
+                a.S_r[r] = B->n_sel_host[sl];
+                MOC_REQUIRE(a.S_r[r] >= 0 && a.S_r[r] <= s_bound(B), "moc_train_steps_runs: n_sel_host[%d] = %d is not a row count of this batch", sl, a.S_r[r]);
+                s_max = a.S_r[r] > s_max ? a.S_r[r] : s_max;
+            }
         }
+        if (s_known) { a.S_host = 0; grid.x = s_max > 0 ? moc_cdiv(s_max, 16) : 1; }
         grid.y = runs->n_runs;
         // fp32 bags: the sixteen-wave kernel is built for the latency of ONE tile per CU; with many runs there are more
         // tiles than the chip holds sixteen-wave workgroups (two per CU), and the four-wave kernel -- the same bits
@@ -3266,7 +3289,11 @@ void tile_region(const moc_batch_t* B, int slide, int64_t* slot0, int* tcap, int
     // the slide's region: cap tiles per class; the kernel's loads are issued before n_sel is known and clamped to the
     // tiles the slide can have at all (at most s_bound selected rows)
     *tcap = moc_cdiv(seg, 16) > 0 ? moc_cdiv(seg, 16) : 1;
-    const int tb_all = moc_cdiv(s_bound(B), 16);
+    int tb_all = moc_cdiv(s_bound(B), 16);
+    if (B->n_sel_host) {                                    // the slide's own tile count: fewer record keys per lane in the step
+        const int sh = B->n_sel_host[slide];
+        if (sh >= 0 && moc_cdiv(sh, 16) < tb_all) tb_all = sh > 0 ? moc_cdiv(sh, 16) : 1;
+    }
     *tb = *tcap < tb_all ? *tcap : tb_all;
     *slot0 = ((base >> 4) + slide) * (int64_t)B->C * TILE_R;
 }

@@ -34,6 +34,7 @@ COMPACT_STATS = os.environ.get("MOC_COMPACT_STATS", "1") != "0"     # wide banks
 RESERVE_CUS = int(os.environ.get("MOC_RESERVE_CUS", "64"))
 # the training step pools among the forward's tile records (moc_meta_ws_t.tile_ws; 0: re-reads every mixed score, round 3)
 TILE_RECORDS = os.environ.get("MOC_TILE_RECORDS", "1") != "0"
+N_SEL_HOST = os.environ.get("MOC_N_SEL_HOST", "1") != "0"            # moc_batch_t.n_sel_host for the train steps (0: never, diagnostic)
 
 # bench.py sets this to a list: every batched score-pass launch then appends
 # (start_event, stop_event, algorithmic_bytes) recorded on the launch stream.
@@ -268,6 +269,12 @@ class SlideBatch:
         self.cu_reserved = None
         self._ws = None
         self.stats_cache = None          # (statistics of every row of X, layout flag): phase A copies instead of reading the bags
+        # moc_batch_t.n_sel_host: a pinned copy of n_sel requested behind every phase A, handed to the train steps once its
+        # event has completed (the look-ahead phase A of a pass ended long before the pass's steps are issued) -- the forward
+        # then takes a slide's S as an argument instead of loading it, launches exactly the workgroups that have rows, and
+        # the step reads fewer record keys per lane.  Masked (training) batches only.
+        self._n_sel_pin = torch.empty(n, dtype=torch.int32).pin_memory() if (N_SEL_HOST and mask is not None) else None
+        self._n_sel_ev = None
 
     def reserve_cus(self, n: int | None = None, ticket: bool | None = None):
         """This batch's score passes stay off `n` compute units (default MOC_RESERVE_CUS) and hand their tiles out by
@@ -322,18 +329,47 @@ class SlideBatch:
         # softmax columns); phase A is the only reader of its own statistics, so the layout is its private choice.
         # for_eval: only meta_forward follows (no train step, no ablation mix): candidates straight from the statistics
         self._layout(COMPACT_STATS and self.Ce > 16, cand_from_stats=bool(for_eval) and CAND_FROM_STATS and self.C > 4)
+        self._n_sel_stale()
         if SCORE_EVENTS is None and self.stats_cache is None:
             check(lib().moc_phase_a(C.byref(self.c), ptr(bank.image), _stream()), "moc_phase_a")
+            self._n_sel_request()
             return
         # same four launches, with events around the score pass
         check(lib().moc_mask_compact(C.byref(self.c), _stream()), "moc_mask_compact")
         self.phase_a_tail(bank)
+
+    _n_sel_pin = None                   # (class defaults: CompactBatch builds its own fields)
+    _n_sel_ev = None
+
+    def _n_sel_stale(self):
+        """n_sel is about to be rewritten: the host copy no longer describes it."""
+        self.c.n_sel_host = None
+        self._n_sel_ev = None
+
+    def _n_sel_request(self):
+        """Behind the launches that write n_sel, on their stream: the asynchronous copy into the pinned buffer and its event."""
+        if self._n_sel_pin is None:
+            return
+        self.c.n_sel_host = None
+        self._n_sel_pin.copy_(self.n_sel, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream_obj())
+        self._n_sel_ev = ev
+
+    def publish_n_sel(self, allow: bool = True):
+        """Called in front of the train steps: moc_batch_t.n_sel_host = the pinned copy when its event has completed (never
+        waited for), else NULL."""
+        ev = self._n_sel_ev
+        ok = allow and ev is not None and ev.query()
+        self.c.n_sel_host = ptr(self._n_sel_pin) if ok else None
+        return ok
 
     def phase_a_head(self, bank: Bank):
         """The first launch of phase A alone -- the kept-row lists from the keep flags (read over PCIe when they are host
         flags) -- for a caller that runs it ahead of the rest (moc_amd.runs)."""
         assert bank.D == self.D and bank.C == self.C and bank.Ce == self.Ce and bank.dtype == self.X.dtype
         self._layout(COMPACT_STATS and self.Ce > 16)
+        self._n_sel_stale()
         check(lib().moc_mask_compact(C.byref(self.c), _stream()), "moc_mask_compact")
 
     def phase_a_tail(self, bank: Bank):
@@ -349,8 +385,10 @@ class SlideBatch:
         else:
             e0, e1 = timed_scores(self, bank)
             SCORE_EVENTS.append((e0, e1, self.kept_rows_host * self.D * self.X.element_size()))
+        self._n_sel_stale()
         self.select()
         self.gather_candidates()
+        self._n_sel_request()
 
     def scores(self, bank: Bank):
         self._layout(False)                      # callers of scores() read `stats` themselves: the full layout
@@ -358,6 +396,7 @@ class SlideBatch:
         check(lib().moc_scores(C.byref(self.c), ptr(bank.image), _stream()), "moc_scores")
 
     def select(self):
+        self._n_sel_stale()
         check(lib().moc_select(C.byref(self.c), _stream()), "moc_select")
 
     def gather_candidates(self, with_feat=False):
@@ -754,6 +793,8 @@ def train_steps(batch: SlideBatch, meta: MetaState, labels: torch.Tensor, slide0
     same coefficient floats, bit-identical parameters."""
     _, ws = batch.meta_ws()
     g = meta.step_graph()
+    # (a pass graph bakes its grids in: the device's n_sel there)
+    batch.publish_n_sel(allow=g is None)
     if g is not None:
         check(lib().moc_train_steps_graph(g, C.byref(batch.c), C.byref(meta.c), C.byref(ws), ptr(labels), slide0, n,
                                           use_bits, _stream()), "moc_train_steps_graph")

@@ -226,6 +226,7 @@ class TrainRuns:
             self._phase_a(self.turn)
         batch = self.batches[self.turn]
         t, ws0 = batch.meta_ws()
+        batch.publish_n_sel()
         self.meta.refresh()
         main = engine.stream_obj()
         ready = None

@@ -1157,6 +1157,33 @@ def _train_epochs(dev, tile_records, C, D, dtype, sizes, j, K, epochs, seed, dis
         E.TILE_RECORDS = keep
 
 
+@pytest.mark.parametrize("C,D,dtype,sizes,j,K", [
+    (2, 512, torch.float32, [3000, 2500, 4100, 2800, 3333], 400, 10),
+    (3, 512, torch.bfloat16, [2000, 2600, 1500, 2200], 300, 10),
+    (2, 512, torch.float32, [40, 18, 9, 300], 400, 10),              # slides of a tile or two, S < K, S = 0 possible
+    (30, 512, torch.bfloat16, [1800, 2200], 100, 10),                 # the wide step behind the sixteen-row forward
+])
+def test_host_known_row_counts_change_no_bit(dev, C, D, dtype, sizes, j, K, monkeypatch):
+    """moc_batch_t.n_sel_host (round 4): from its second pass on, train() hands the steps a pinned copy of n_sel whose copy
+    event has completed -- the forward takes S as an argument (one dependent load less), launches exactly the workgroups
+    that have rows, the step reads fewer record keys per lane.  Four passes with it and four with the field left NULL:
+    the same losses, pooled rows, parameters and moments, bit for bit; and the copy really was handed over."""
+    E = _engine()
+    used = []
+    orig = E.SlideBatch.publish_n_sel
+    monkeypatch.setattr(E.SlideBatch, "publish_n_sel", lambda self, allow=True: used.append(orig(self, allow)) or used[-1])
+    a = _train_epochs(dev, True, C, D, dtype, sizes, j, K, 4, 6161 + C)
+    assert any(used), "the host copy of n_sel was never handed to the train steps"
+    monkeypatch.setattr(E.SlideBatch, "publish_n_sel", lambda self, allow=True: orig(self, False))
+    b = _train_epochs(dev, True, C, D, dtype, sizes, j, K, 4, 6161 + C)
+    for e in range(4):
+        np.testing.assert_array_equal(a["loss"][e], b["loss"][e])
+        np.testing.assert_array_equal(a["pooled"][e], b["pooled"][e])
+        np.testing.assert_array_equal(a["topk"][e], b["topk"][e])
+    for k in ("params", "m", "v"):
+        np.testing.assert_array_equal(a[k], b[k])
+
+
 @pytest.mark.parametrize("C,D,dtype,sizes,j,K,discard", [
     (2, 512, torch.float32, [3000, 2500, 4100, 2800, 3333], 400, 10, ()),
     (2, 512, torch.bfloat16, [3000, 2500, 4100], 400, 10, ("delta_diff",)),
