@@ -1821,7 +1821,8 @@ struct TileStepArgs {
     // ---- what this thread steps
     const int64_t* labels;
     int PS_CAP, xdt;
-    int tail_inside, pad0_;         // != 0: no tail workgroups (grid.x = D / 256), column block 0 owns the hidden unit's small elements too
+    int tail_inside;                // != 0: no tail workgroups (grid.x = D / 256), column block 0 owns the hidden unit's small elements too
+    int S_host;                     // the slide's selected-row count when the host knows it (one run's launch; -1: n_sel[b])
     float *W1, *m_W1, *v_W1;
     const float* W2;
     float *b1, *m_b1, *v_b1, *b2, *m_b2, *v_b2, *m_W2, *v_W2;
@@ -1995,7 +1996,7 @@ __global__ __launch_bounds__(256, 4) void pool_w1_step_tiles_kernel(ArgsT args) 
     }
     AdamCoef ak = a.adam;
     if (a.adam_tab) ak = a.adam_tab[a.adam_ctr[0] + a.adam_pos];
-    const int S = a.n_sel[b];
+    const int S = (!RUNS && a.S_host >= 0) ? a.S_host : a.n_sel[b];
     const int y = (int)a.labels[b];
     const int k = K < S ? K : S;
     // LDS carve: the 16-byte things first
@@ -3311,6 +3312,7 @@ TileStepArgs tile_step_args(const moc_batch_t* B, const moc_meta_t* M, const moc
     ta.m_W2 = M->m_W2; ta.v_W2 = M->v_W2;
     ta.base = B->row_off_host[slide]; ta.adam = k;
     ta.row_off = B->row_off; ta.prefetch_next = 0;
+    ta.S_host = B->n_sel_host ? B->n_sel_host[slide] : -1;
     ta.sink_off = (int)(tiles_step_smem(B, ta.PS_CAP) - TILES_SINK);
     if (tab) { ta.adam_tab = tab->tab; ta.adam_ctr = tab->ctr; ta.adam_pos = tab->pos; }
     ta.apply_adam = apply_adam; ta.use_bits = use_bits; ta.img_dt = B->dtype;
